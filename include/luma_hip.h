@@ -1,0 +1,170 @@
+/* luma_hip.h -- C-ABI of the MI355X (gfx950) render-loop backend for connorjlink/raytracer
+ * ("Luma").  One shared library, libluma_hip.so, replaces the inner loops of
+ * Renderer::render_to (Renderer.cpp:366-471) and Camera::recompute_rays (Camera.cpp:185-216)
+ * behind the reference's own Renderer / Camera API.  Plain C types only; no exceptions cross
+ * this boundary; every function returns 0 or a negative LUMA_E_* code.
+ *
+ * The reference has no FFI: its seam is the C++ method
+ *     void Renderer::render_to(std::uint32_t* target, olc::PixelGameEngine*)   renderer.h:76
+ * plus the global luma::_options (arguments.h:43).  Each entry point below names the
+ * reference lines it stands in for.  INTEGRATION.md shows the reference-side glue.
+ *
+ * Threading: a context is used from one host thread at a time (the reference is single
+ * threaded, Renderer.cpp:392).  Two calls on one context must not overlap.
+ */
+#ifndef LUMA_HIP_H
+#define LUMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LUMA_HIP_ABI_VERSION 1
+
+enum {
+    LUMA_OK       = 0,
+    LUMA_E_ARG    = -1,  /* bad argument (null pointer, zero size, out-of-range value) */
+    LUMA_E_HIP    = -2,  /* a HIP runtime call failed; luma_hip_last_error() has the text */
+    LUMA_E_NOMEM  = -3,  /* device or host allocation failed */
+    LUMA_E_STATE  = -4,  /* call order: scene / camera / frame not set */
+    LUMA_E_RCCL   = -5   /* a RCCL call failed (multi-device contexts) */
+};
+
+/* luma::RenderMode, arguments.h:9-13 */
+enum { LUMA_MODE_RAYTRACE = 0, LUMA_MODE_PATHTRACE = 1 };
+
+/* Behaviour switches.  All zero == the committed reference behaviour. */
+enum {
+    LUMA_FLAG_NOISE_OFF       = 1u, /* no direction / roughness noise, no RNG (the reference has no such path: Renderer.cpp:302) */
+    LUMA_FLAG_ORIGIN_FROM_HIT = 2u, /* bounce rays start at the hit point + .001 normal (Renderer.cpp:221-222) instead of camera.pos (:303) */
+    LUMA_FLAG_CLAMP_PACK      = 4u, /* clamp channels to [0,255] before packing (Renderer.cpp:44-55 does not) */
+    LUMA_FLAG_NO_SHOW_DEPTH   = 8u  /* skip the in-focus x1.2 (Renderer.cpp:448-454) regardless of camera.show_depth */
+};
+
+typedef struct luma_ctx luma_ctx;
+
+/* == luma::Sphere + luma::Material, renderer.h:23-36: 40 bytes, same field order, so a
+ * std::vector<Sphere>::data() can be passed as is. */
+typedef struct {
+    float cx, cy, cz, radius;
+    float dr, dg, db;
+    float albedo, metallic, roughness;
+} luma_sphere;
+
+/* What the loop reads of luma::Camera (camera.h:23-37).  Matrices are the reference's
+ * fx::mat4 m[i][j] flattened as [i*4+j]. */
+typedef struct {
+    float pos[3];
+    float proj_inv[16];   /* Camera::projection_inverse */
+    float view_inv[16];   /* Camera::view_inverse */
+    float focus_depth;    /* Camera::depth */
+    uint32_t show_depth;  /* Camera::show_depth */
+} luma_camera;
+
+/* luma::Options (arguments.h:35-41) snapshot + per-call additions. */
+typedef struct {
+    uint32_t width, height;            /* full frame, _options.width/height */
+    uint32_t samples, bounces, paths;  /* _options.samples/bounces/paths */
+    uint32_t mode;                     /* LUMA_MODE_* */
+    uint32_t spp;                      /* frames accumulated by this call (>= 1); one render_to == 1 */
+    uint32_t flags;                    /* LUMA_FLAG_* */
+    uint64_t seed;                     /* counter-RNG seed */
+} luma_params;
+
+typedef struct {
+    double   kernel_ms;     /* render kernel(s), HIP events on the context's stream */
+    double   gather_ms;     /* device->host (and inter-device) copy of the frame */
+    double   total_ms;      /* wall clock of the call */
+    uint64_t rays;          /* trace_ray invocations executed (Renderer.cpp:234) */
+    uint64_t sphere_tests;  /* ray-sphere tests executed (loop at Renderer.cpp:242) */
+} luma_stats;
+
+/* ---- lifetime ------------------------------------------------------------------ */
+
+/* Stands in for Renderer::Renderer (Renderer.cpp:163-170): owns the device-side
+ * accumulated_data.  device_id < 0 selects the current HIP device. */
+int  luma_hip_create(luma_ctx** out, int device_id);
+void luma_hip_destroy(luma_ctx* ctx);
+
+/* ---- inputs -------------------------------------------------------------------- */
+
+/* Renderer::spheres (renderer.h:70), in vector order (ties go to the lower index,
+ * Renderer.cpp:266).  AoS in, structure-of-arrays on the device. */
+int luma_hip_set_scene(luma_ctx* ctx, const luma_sphere* spheres, uint32_t n);
+
+/* camera.pos / projection_inverse / view_inverse / depth / show_depth as read at
+ * Renderer.cpp:293-294,413-414,425,448 and Camera.cpp:203,212.  Does not reset the
+ * accumulation: call luma_hip_reset() for the camera.moved branch. */
+int luma_hip_set_camera(luma_ctx* ctx, const luma_camera* cam);
+
+/* Frame geometry.  The context renders rows [row_begin,row_end) of a width x height frame
+ * (a scanline band; the whole frame for a single device).  Allocates and zeroes the band's
+ * accumulation planes (Renderer.cpp:166-169) and resets the frame counter. */
+int luma_hip_set_frame(luma_ctx* ctx, uint32_t width, uint32_t height,
+                       uint32_t row_begin, uint32_t row_end);
+
+/* The camera.moved branch, Renderer.cpp:377-390: frame_count = 1, accumulated_data = 0. */
+int luma_hip_reset(luma_ctx* ctx);
+
+/* ---- the render loop ----------------------------------------------------------- */
+
+/* Renderer::render_to (Renderer.cpp:366-471) for params->spp successive frames of the
+ * context's band.  target_host receives the band's pixels, (row_end-row_begin)*width
+ * uint32 0x00RRGGBB, row-major (Renderer.cpp:461).  Synchronous.  stats may be NULL. */
+int luma_hip_render(luma_ctx* ctx, const luma_params* params, uint32_t* target_host,
+                    luma_stats* stats);
+
+/* Same, but the band is left in device memory: target_dev is a device pointer to
+ * (row_end-row_begin)*width uint32 (NULL: the context's own buffer, see
+ * luma_hip_target_device).  Work is enqueued on `stream` (a hipStream_t; NULL = the
+ * context's stream) and the call returns without waiting unless stats is non-NULL. */
+int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* target_dev,
+                           void* stream, luma_stats* stats);
+
+/* Device pointer of the context's own band framebuffer (valid until set_frame/destroy). */
+int luma_hip_target_device(luma_ctx* ctx, uint32_t** target_dev);
+
+/* ---- read-back hooks ----------------------------------------------------------- */
+
+/* Renderer::accumulated_data for the band as the reference lays it out: W*rows*3 floats,
+ * AoS rgb (renderer.h:56). */
+int luma_hip_read_accum(luma_ctx* ctx, float* rgb_host);
+
+/* Frames accumulated since the last reset (== frame_count - 1, renderer.h:53). */
+int luma_hip_frame_index(luma_ctx* ctx, uint32_t* frame_index);
+
+/* Camera::recompute_rays (Camera.cpp:185-216) for the band, run as its own kernel:
+ * rays_host receives rows*W*3 floats.  The render kernel computes the same directions
+ * in registers and never reads such a table. */
+int luma_hip_generate_rays(luma_ctx* ctx, float* rays_host);
+
+/* ---- host-side camera and scene helpers (no GPU work) -------------------------- */
+
+/* Camera::Camera (Camera.cpp:77-90) + recompute_projection/recompute_view (:169-183):
+ * pos (0,0,0), dir (0,0,-1), depth 10, show_depth on (camera.h:33-35). */
+int luma_camera_default(float fov_deg, float nearclip, float farclip,
+                        uint32_t width, uint32_t height, luma_camera* out);
+
+/* Camera::update's pose arithmetic (Camera.cpp:135-152) + recompute_view (:176-183). */
+int luma_camera_from_pose(float fov_deg, float nearclip, float farclip,
+                          uint32_t width, uint32_t height,
+                          const float pos[3], float pitch, float yaw, luma_camera* out);
+
+/* The reference's hard-coded scene, renderer.h:62-70, order s,a,q,r,t.  out has room for 5. */
+int luma_scene_default(luma_sphere* out);
+
+/* Build-defined large scene: sphere 0 = ground, the rest from
+ * the counter RNG.  No counterpart in the reference. */
+int luma_scene_synthetic(luma_sphere* out, uint32_t n, uint64_t seed);
+
+/* ---- diagnostics --------------------------------------------------------------- */
+const char* luma_hip_strerror(int code);
+const char* luma_hip_last_error(void);   /* thread-local text of the last failure */
+int         luma_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

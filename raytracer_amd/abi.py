@@ -1,0 +1,223 @@
+"""ctypes binding of libluma_hip.so (include/luma_hip.h), one Python symbol per C entry point.
+
+This is plumbing for the tests and bench.py; the product is the shared library.  There is
+no CPU fallback: if the library is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libluma_hip.so")
+
+OK, E_ARG, E_HIP, E_NOMEM, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5
+MODE_RAYTRACE, MODE_PATHTRACE = 0, 1
+FLAG_NOISE_OFF, FLAG_ORIGIN_FROM_HIT, FLAG_CLAMP_PACK, FLAG_NO_SHOW_DEPTH = 1, 2, 4, 8
+
+# every symbol include/luma_hip.h declares (checked by tests/test_abi_symbols.py)
+SYMBOLS = [
+    "luma_hip_create", "luma_hip_destroy", "luma_hip_set_scene", "luma_hip_set_camera",
+    "luma_hip_set_frame", "luma_hip_reset", "luma_hip_render", "luma_hip_render_device",
+    "luma_hip_target_device", "luma_hip_read_accum", "luma_hip_frame_index",
+    "luma_hip_generate_rays", "luma_camera_default", "luma_camera_from_pose",
+    "luma_scene_default", "luma_scene_synthetic", "luma_hip_strerror", "luma_hip_last_error",
+    "luma_hip_abi_version",
+]
+
+
+class Sphere(C.Structure):
+    _fields_ = [("cx", C.c_float), ("cy", C.c_float), ("cz", C.c_float), ("radius", C.c_float),
+                ("dr", C.c_float), ("dg", C.c_float), ("db", C.c_float),
+                ("albedo", C.c_float), ("metallic", C.c_float), ("roughness", C.c_float)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("proj_inv", C.c_float * 16), ("view_inv", C.c_float * 16),
+                ("focus_depth", C.c_float), ("show_depth", C.c_uint32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32),
+                ("bounces", C.c_uint32), ("paths", C.c_uint32), ("mode", C.c_uint32),
+                ("spp", C.c_uint32), ("flags", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double), ("gather_ms", C.c_double), ("total_ms", C.c_double),
+                ("rays", C.c_uint64), ("sphere_tests", C.c_uint64)]
+
+
+class LumaError(RuntimeError):
+    def __init__(self, code, where, detail):
+        super().__init__(f"{where}: {detail} (code {code})")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libluma_hip.so.  Import torch BEFORE calling this in a process that uses torch,
+    so both share torch's HIP runtime (same libamdhip64 soname)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    ctx, ctxp = C.c_void_p, C.POINTER(C.c_void_p)
+    f32p, u32p = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+    sig = {
+        "luma_hip_create": (C.c_int, [ctxp, C.c_int]),
+        "luma_hip_destroy": (None, [ctx]),
+        "luma_hip_set_scene": (C.c_int, [ctx, C.POINTER(Sphere), C.c_uint32]),
+        "luma_hip_set_camera": (C.c_int, [ctx, C.POINTER(Camera)]),
+        "luma_hip_set_frame": (C.c_int, [ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "luma_hip_reset": (C.c_int, [ctx]),
+        "luma_hip_render": (C.c_int, [ctx, C.POINTER(Params), u32p, C.POINTER(Stats)]),
+        "luma_hip_render_device": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+        "luma_hip_target_device": (C.c_int, [ctx, C.POINTER(C.c_void_p)]),
+        "luma_hip_read_accum": (C.c_int, [ctx, f32p]),
+        "luma_hip_frame_index": (C.c_int, [ctx, u32p]),
+        "luma_hip_generate_rays": (C.c_int, [ctx, f32p]),
+        "luma_camera_default": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(Camera)]),
+        "luma_camera_from_pose": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, f32p,
+                                            C.c_float, C.c_float, C.POINTER(Camera)]),
+        "luma_scene_default": (C.c_int, [C.POINTER(Sphere)]),
+        "luma_scene_synthetic": (C.c_int, [C.POINTER(Sphere), C.c_uint32, C.c_uint64]),
+        "luma_hip_strerror": (C.c_char_p, [C.c_int]),
+        "luma_hip_last_error": (C.c_char_p, []),
+        "luma_hip_abi_version": (C.c_int, []),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def check(code, where):
+    if code != OK:
+        L = lib()
+        raise LumaError(code, where, (L.luma_hip_last_error() or b"").decode() or L.luma_hip_strerror(code).decode())
+
+
+def _f32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def default_scene():
+    arr = (Sphere * 5)()
+    check(lib().luma_scene_default(arr), "luma_scene_default")
+    return arr
+
+
+def synthetic_scene(n, seed=0x4C554D41):
+    arr = (Sphere * n)()
+    check(lib().luma_scene_synthetic(arr, n, seed), "luma_scene_synthetic")
+    return arr
+
+
+def default_camera(width, height, fov=70.0, near=0.1, far=100.0):
+    cam = Camera()
+    check(lib().luma_camera_default(fov, near, far, width, height, C.byref(cam)), "luma_camera_default")
+    return cam
+
+
+def camera_from_pose(width, height, pos, pitch, yaw, fov=70.0, near=0.1, far=100.0):
+    cam = Camera()
+    p = np.asarray(pos, dtype=np.float32)
+    check(lib().luma_camera_from_pose(fov, near, far, width, height, _f32p(p), pitch, yaw, C.byref(cam)),
+          "luma_camera_from_pose")
+    return cam
+
+
+def make_params(width, height, spp=1, bounces=1, paths=1, samples=1, mode=MODE_RAYTRACE, flags=0,
+                seed=0x4C554D41):
+    return Params(width, height, samples, bounces, paths, mode, spp, flags, seed)
+
+
+class Context:
+    """Owns one luma_ctx (one device, one scanline band)."""
+
+    def __init__(self, device_id=-1):
+        self._h = C.c_void_p()
+        check(lib().luma_hip_create(C.byref(self._h), device_id), "luma_hip_create")
+        self.width = self.height = self.row_begin = self.row_end = 0
+
+    def close(self):
+        if self._h:
+            lib().luma_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scene(self, spheres):
+        n = len(spheres)
+        check(lib().luma_hip_set_scene(self._h, spheres if n else None, n), "luma_hip_set_scene")
+
+    def set_camera(self, cam):
+        check(lib().luma_hip_set_camera(self._h, C.byref(cam)), "luma_hip_set_camera")
+
+    def set_frame(self, width, height, row_begin=0, row_end=None):
+        row_end = height if row_end is None else row_end
+        check(lib().luma_hip_set_frame(self._h, width, height, row_begin, row_end), "luma_hip_set_frame")
+        self.width, self.height, self.row_begin, self.row_end = width, height, row_begin, row_end
+
+    def reset(self):
+        check(lib().luma_hip_reset(self._h), "luma_hip_reset")
+
+    @property
+    def rows(self):
+        return self.row_end - self.row_begin
+
+    def render(self, params, want_stats=True):
+        """luma_hip_render: returns (band uint32 [rows, W], Stats)."""
+        out = np.empty((self.rows, self.width), dtype=np.uint32)
+        st = Stats()
+        check(lib().luma_hip_render(self._h, C.byref(params), _u32p(out), C.byref(st) if want_stats else None),
+              "luma_hip_render")
+        return out, st
+
+    def render_device(self, params, target_ptr=None, stream=None, want_stats=False):
+        """luma_hip_render_device: band stays in HBM.  Returns Stats (zeros unless want_stats)."""
+        st = Stats()
+        check(lib().luma_hip_render_device(self._h, C.byref(params), target_ptr, stream,
+                                           C.byref(st) if want_stats else None), "luma_hip_render_device")
+        return st
+
+    def target_device(self):
+        p = C.c_void_p()
+        check(lib().luma_hip_target_device(self._h, C.byref(p)), "luma_hip_target_device")
+        return p.value
+
+    def read_accum(self):
+        out = np.empty((self.rows, self.width, 3), dtype=np.float32)
+        check(lib().luma_hip_read_accum(self._h, _f32p(out)), "luma_hip_read_accum")
+        return out
+
+    def frame_index(self):
+        v = C.c_uint32()
+        check(lib().luma_hip_frame_index(self._h, C.byref(v)), "luma_hip_frame_index")
+        return v.value
+
+    def generate_rays(self):
+        out = np.empty((self.rows, self.width, 3), dtype=np.float32)
+        check(lib().luma_hip_generate_rays(self._h, _f32p(out)), "luma_hip_generate_rays")
+        return out

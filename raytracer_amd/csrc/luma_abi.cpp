@@ -1,0 +1,484 @@
+// luma_abi.cpp -- the C-ABI of include/luma_hip.h: context, device memory, launches.
+// No exceptions cross the boundary; every HIP failure becomes LUMA_E_HIP with a message.
+#include "luma_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "luma_host.h"
+#include "luma_kernels.h"
+
+namespace {
+
+thread_local char g_last_error[512] = "";
+
+int fail(int code, const char* what, const char* detail)
+{
+    std::snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, detail ? detail : "");
+    return code;
+}
+
+#define LUMA_HIP_TRY(expr)                                                         \
+    do {                                                                           \
+        hipError_t e_ = (expr);                                                    \
+        if (e_ != hipSuccess) {                                                    \
+            return fail(e_ == hipErrorOutOfMemory ? LUMA_E_NOMEM : LUMA_E_HIP,     \
+                        #expr, hipGetErrorString(e_));                             \
+        }                                                                          \
+    } while (0)
+
+// Makes ctx's device current for the scope of one ABI call and restores the caller's.
+class DeviceScope {
+public:
+    explicit DeviceScope(int device) : ok_(false), prev_(-1)
+    {
+        if (hipGetDevice(&prev_) != hipSuccess) { return; }
+        if (prev_ != device && hipSetDevice(device) != hipSuccess) { return; }
+        ok_ = true;
+    }
+    ~DeviceScope()
+    {
+        if (ok_ && prev_ >= 0) {
+            int now = -1;
+            if (hipGetDevice(&now) == hipSuccess && now != prev_) { (void)hipSetDevice(prev_); }
+        }
+    }
+    bool ok() const { return ok_; }
+
+private:
+    bool ok_;
+    int prev_;
+};
+
+template <typename T>
+void free_dev(T*& p)
+{
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+}  // namespace
+
+struct luma_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+
+    // scene: structure-of-arrays geometry + packed material vectors
+    uint32_t n_spheres = 0;
+    float* d_cx = nullptr;
+    float* d_cy = nullptr;
+    float* d_cz = nullptr;
+    float* d_rad = nullptr;
+    float4* d_mat0 = nullptr;
+    float2* d_mat1 = nullptr;
+    float4* d_records = nullptr;   // 2n scan records, rebuilt when scene or camera.pos changes
+    bool records_stale = true;
+    bool have_scene = false;
+
+    luma_camera camera{};
+    bool have_camera = false;
+
+    // frame / band
+    uint32_t width = 0, height = 0, row_begin = 0, row_end = 0;
+    float* d_acc = nullptr;        // 3 planes of rows*width
+    uint32_t* d_target = nullptr;  // rows*width
+    uint32_t frame_index = 0;
+    bool have_frame = false;
+
+    unsigned long long* d_counters = nullptr;  // [0] rays
+    unsigned long long* h_counters = nullptr;  // pinned
+
+    size_t band_pixels() const { return static_cast<size_t>(row_end - row_begin) * width; }
+};
+
+namespace {
+
+int check_params(const luma_ctx* ctx, const luma_params* p)
+{
+    if (!ctx || !p) { return fail(LUMA_E_ARG, "render", "null context or params"); }
+    if (!ctx->have_scene) { return fail(LUMA_E_STATE, "render", "luma_hip_set_scene not called"); }
+    if (!ctx->have_camera) { return fail(LUMA_E_STATE, "render", "luma_hip_set_camera not called"); }
+    if (!ctx->have_frame) { return fail(LUMA_E_STATE, "render", "luma_hip_set_frame not called"); }
+    if (p->width != ctx->width || p->height != ctx->height) {
+        return fail(LUMA_E_ARG, "render", "params width/height differ from luma_hip_set_frame");
+    }
+    if (p->spp == 0) { return fail(LUMA_E_ARG, "render", "spp must be >= 1"); }
+    if (p->mode != LUMA_MODE_RAYTRACE && p->mode != LUMA_MODE_PATHTRACE) {
+        return fail(LUMA_E_ARG, "render", "mode must be LUMA_MODE_RAYTRACE or LUMA_MODE_PATHTRACE");
+    }
+    if (p->mode == LUMA_MODE_PATHTRACE && p->samples == 0) {
+        return fail(LUMA_E_ARG, "render", "samples must be >= 1 in pathtrace mode (1/samples, Renderer.cpp:212)");
+    }
+    if (p->bounces > 4096 || p->paths > 4096) {
+        return fail(LUMA_E_ARG, "render", "bounces/paths out of range (max 4096)");
+    }
+    if (static_cast<uint64_t>(ctx->frame_index) + p->spp > 0xFFFFFFFFull) {
+        return fail(LUMA_E_ARG, "render", "frame counter would overflow; call luma_hip_reset");
+    }
+    return LUMA_OK;
+}
+
+luma::RenderArgs make_args(const luma_ctx* ctx, const luma_params* p, uint32_t* target_dev)
+{
+    luma::RenderArgs a{};
+    a.width = ctx->width;
+    a.height = ctx->height;
+    a.row_begin = ctx->row_begin;
+    a.row_end = ctx->row_end;
+    if (p) {
+        a.bounces = p->bounces;
+        a.paths = p->paths;
+        a.mode = p->mode;
+        a.flags = p->flags;
+        a.spp = p->spp;
+        a.frame_index = ctx->frame_index;
+        a.frame_count_last = static_cast<float>(ctx->frame_index + p->spp - 1u) + 1.f;   // renderer.h:53, Renderer.cpp:470
+        a.inv_samples = p->samples ? 1.f / static_cast<float>(p->samples) : 0.f;         // Renderer.cpp:212
+        luma::seed_keys(p->seed, a.key);
+        a.show_depth = (ctx->camera.show_depth && !(p->flags & LUMA_FLAG_NO_SHOW_DEPTH)) ? 1u : 0u;
+    }
+    std::memcpy(a.cam_pos, ctx->camera.pos, sizeof a.cam_pos);
+    std::memcpy(a.proj_inv, ctx->camera.proj_inv, sizeof a.proj_inv);
+    std::memcpy(a.view_inv, ctx->camera.view_inv, sizeof a.view_inv);
+    a.focus_depth = ctx->camera.focus_depth;
+    a.n_spheres = ctx->n_spheres;
+    a.records = ctx->d_records;
+    a.mat0 = ctx->d_mat0;
+    a.mat1 = ctx->d_mat1;
+    const size_t plane = ctx->band_pixels();
+    a.acc[0] = ctx->d_acc;
+    a.acc[1] = ctx->d_acc ? ctx->d_acc + plane : nullptr;
+    a.acc[2] = ctx->d_acc ? ctx->d_acc + 2 * plane : nullptr;
+    a.target = target_dev;
+    a.counters = ctx->d_counters;
+    return a;
+}
+
+int refresh_records(luma_ctx* ctx, hipStream_t stream)
+{
+    if (!ctx->records_stale) { return LUMA_OK; }
+    LUMA_HIP_TRY(luma::launch_prepare_records(ctx->d_cx, ctx->d_cy, ctx->d_cz, ctx->d_rad, ctx->n_spheres,
+                                              ctx->camera.pos, ctx->d_records, stream));
+    ctx->records_stale = false;
+    return LUMA_OK;
+}
+
+// Enqueue one render call on `stream`.  Events bracket the render kernel only.
+int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hipStream_t stream)
+{
+    if (int rc = refresh_records(ctx, stream)) { return rc; }
+    LUMA_HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long), stream));
+    const luma::RenderArgs args = make_args(ctx, p, target_dev);
+    LUMA_HIP_TRY(hipEventRecord(ctx->ev_begin, stream));
+    LUMA_HIP_TRY(luma::launch_render(args, stream));
+    LUMA_HIP_TRY(hipEventRecord(ctx->ev_end, stream));
+    ctx->frame_index += p->spp;
+    return LUMA_OK;
+}
+
+int collect_stats(luma_ctx* ctx, hipStream_t stream, luma_stats* stats)
+{
+    LUMA_HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost, stream));
+    LUMA_HIP_TRY(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    LUMA_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+    stats->kernel_ms = ms;
+    stats->rays = ctx->h_counters[0];
+    stats->sphere_tests = stats->rays * ctx->n_spheres;   // every ray scans every sphere (Renderer.cpp:242)
+    return LUMA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int luma_hip_abi_version(void) { return LUMA_HIP_ABI_VERSION; }
+
+const char* luma_hip_last_error(void) { return g_last_error; }
+
+const char* luma_hip_strerror(int code)
+{
+    switch (code) {
+        case LUMA_OK:      return "ok";
+        case LUMA_E_ARG:   return "invalid argument";
+        case LUMA_E_HIP:   return "HIP runtime error";
+        case LUMA_E_NOMEM: return "out of memory";
+        case LUMA_E_STATE: return "scene, camera or frame not set";
+        case LUMA_E_RCCL:  return "RCCL error";
+        default:           return "unknown error";
+    }
+}
+
+int luma_hip_create(luma_ctx** out, int device_id)
+{
+    if (!out) { return fail(LUMA_E_ARG, "luma_hip_create", "null out pointer"); }
+    *out = nullptr;
+    int count = 0;
+    LUMA_HIP_TRY(hipGetDeviceCount(&count));
+    if (count <= 0) { return fail(LUMA_E_HIP, "luma_hip_create", "no HIP device visible"); }
+    if (device_id < 0) { LUMA_HIP_TRY(hipGetDevice(&device_id)); }
+    if (device_id >= count) { return fail(LUMA_E_ARG, "luma_hip_create", "device_id out of range"); }
+
+    luma_ctx* ctx = new (std::nothrow) luma_ctx();
+    if (!ctx) { return fail(LUMA_E_NOMEM, "luma_hip_create", "host allocation failed"); }
+    ctx->device = device_id;
+    DeviceScope scope(device_id);
+    if (!scope.ok()) { delete ctx; return fail(LUMA_E_HIP, "luma_hip_create", "hipSetDevice failed"); }
+
+    auto bail = [&](hipError_t e, const char* what) {
+        int rc = fail(e == hipErrorOutOfMemory ? LUMA_E_NOMEM : LUMA_E_HIP, what, hipGetErrorString(e));
+        luma_hip_destroy(ctx);
+        return rc;
+    };
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { return bail(e, "hipStreamCreate"); }
+    if ((e = hipEventCreate(&ctx->ev_begin)) != hipSuccess) { return bail(e, "hipEventCreate"); }
+    if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) { return bail(e, "hipEventCreate"); }
+    if ((e = hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long))) != hipSuccess) { return bail(e, "hipMalloc(counters)"); }
+    if ((e = hipHostMalloc(&ctx->h_counters, 2 * sizeof(unsigned long long))) != hipSuccess) { return bail(e, "hipHostMalloc(counters)"); }
+    *out = ctx;
+    return LUMA_OK;
+}
+
+void luma_hip_destroy(luma_ctx* ctx)
+{
+    if (!ctx) { return; }
+    DeviceScope scope(ctx->device);
+    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    free_dev(ctx->d_cx); free_dev(ctx->d_cy); free_dev(ctx->d_cz); free_dev(ctx->d_rad);
+    free_dev(ctx->d_mat0); free_dev(ctx->d_mat1); free_dev(ctx->d_records);
+    free_dev(ctx->d_acc); free_dev(ctx->d_target); free_dev(ctx->d_counters);
+    if (ctx->h_counters) { (void)hipHostFree(ctx->h_counters); }
+    if (ctx->ev_begin) { (void)hipEventDestroy(ctx->ev_begin); }
+    if (ctx->ev_end) { (void)hipEventDestroy(ctx->ev_end); }
+    if (ctx->stream) { (void)hipStreamDestroy(ctx->stream); }
+    delete ctx;
+}
+
+int luma_hip_set_scene(luma_ctx* ctx, const luma_sphere* spheres, uint32_t n)
+{
+    if (!ctx) { return fail(LUMA_E_ARG, "luma_hip_set_scene", "null context"); }
+    if (n > 0 && !spheres) { return fail(LUMA_E_ARG, "luma_hip_set_scene", "null sphere array"); }
+    if (n > (1u << 24)) { return fail(LUMA_E_ARG, "luma_hip_set_scene", "too many spheres (max 2^24)"); }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_set_scene", "hipSetDevice failed"); }
+    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+    free_dev(ctx->d_cx); free_dev(ctx->d_cy); free_dev(ctx->d_cz); free_dev(ctx->d_rad);
+    free_dev(ctx->d_mat0); free_dev(ctx->d_mat1); free_dev(ctx->d_records);
+    ctx->n_spheres = n;
+    ctx->have_scene = true;
+    ctx->records_stale = true;
+    if (n == 0) { return LUMA_OK; }   // empty scene: every ray misses (Renderer.cpp:276)
+
+    // AoS (renderer.h:23-36) -> SoA geometry + packed material vectors
+    std::vector<float> cx(n), cy(n), cz(n), rad(n);
+    std::vector<float4> m0(n);
+    std::vector<float2> m1(n);
+    for (uint32_t i = 0; i < n; i++) {
+        const luma_sphere& s = spheres[i];
+        cx[i] = s.cx; cy[i] = s.cy; cz[i] = s.cz; rad[i] = s.radius;
+        m0[i] = make_float4(s.dr, s.dg, s.db, s.albedo);
+        m1[i] = make_float2(s.metallic, s.roughness);
+    }
+    const size_t fb = n * sizeof(float);
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_cx, fb));
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_cy, fb));
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_cz, fb));
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_rad, fb));
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_mat0, n * sizeof(float4)));
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_mat1, n * sizeof(float2)));
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_records, 2 * static_cast<size_t>(n) * sizeof(float4)));
+    LUMA_HIP_TRY(hipMemcpy(ctx->d_cx, cx.data(), fb, hipMemcpyHostToDevice));
+    LUMA_HIP_TRY(hipMemcpy(ctx->d_cy, cy.data(), fb, hipMemcpyHostToDevice));
+    LUMA_HIP_TRY(hipMemcpy(ctx->d_cz, cz.data(), fb, hipMemcpyHostToDevice));
+    LUMA_HIP_TRY(hipMemcpy(ctx->d_rad, rad.data(), fb, hipMemcpyHostToDevice));
+    LUMA_HIP_TRY(hipMemcpy(ctx->d_mat0, m0.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    LUMA_HIP_TRY(hipMemcpy(ctx->d_mat1, m1.data(), n * sizeof(float2), hipMemcpyHostToDevice));
+    return LUMA_OK;
+}
+
+int luma_hip_set_camera(luma_ctx* ctx, const luma_camera* cam)
+{
+    if (!ctx || !cam) { return fail(LUMA_E_ARG, "luma_hip_set_camera", "null argument"); }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_set_camera", "hipSetDevice failed"); }
+    // the scan records embed camera.pos; in-flight launches hold the old ones
+    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!ctx->have_camera || std::memcmp(ctx->camera.pos, cam->pos, sizeof cam->pos) != 0) {
+        ctx->records_stale = true;
+    }
+    ctx->camera = *cam;
+    ctx->have_camera = true;
+    return LUMA_OK;
+}
+
+int luma_hip_set_frame(luma_ctx* ctx, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end)
+{
+    if (!ctx) { return fail(LUMA_E_ARG, "luma_hip_set_frame", "null context"); }
+    if (width == 0 || height == 0) { return fail(LUMA_E_ARG, "luma_hip_set_frame", "zero width or height"); }
+    if (row_begin >= row_end || row_end > height) {
+        return fail(LUMA_E_ARG, "luma_hip_set_frame", "need row_begin < row_end <= height");
+    }
+    if (static_cast<uint64_t>(width) * height > 0x7FFFFFFFull) {
+        return fail(LUMA_E_ARG, "luma_hip_set_frame", "frame larger than 2^31 pixels");
+    }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_set_frame", "hipSetDevice failed"); }
+    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_dev(ctx->d_acc);
+    free_dev(ctx->d_target);
+    ctx->have_frame = false;
+    ctx->width = width; ctx->height = height;
+    ctx->row_begin = row_begin; ctx->row_end = row_end;
+    const size_t px = ctx->band_pixels();
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_acc, 3 * px * sizeof(float)));
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_target, px * sizeof(uint32_t)));
+    ctx->have_frame = true;
+    return luma_hip_reset(ctx);
+}
+
+int luma_hip_reset(luma_ctx* ctx)
+{
+    if (!ctx) { return fail(LUMA_E_ARG, "luma_hip_reset", "null context"); }
+    if (!ctx->have_frame) { return fail(LUMA_E_STATE, "luma_hip_reset", "luma_hip_set_frame not called"); }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_reset", "hipSetDevice failed"); }
+    const size_t px = ctx->band_pixels();
+    LUMA_HIP_TRY(hipMemsetAsync(ctx->d_acc, 0, 3 * px * sizeof(float), ctx->stream));      // Renderer.cpp:381-387
+    LUMA_HIP_TRY(hipMemsetAsync(ctx->d_target, 0, px * sizeof(uint32_t), ctx->stream));
+    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->frame_index = 0;                                                                  // Renderer.cpp:379
+    return LUMA_OK;
+}
+
+int luma_hip_render(luma_ctx* ctx, const luma_params* params, uint32_t* target_host, luma_stats* stats)
+{
+    if (int rc = check_params(ctx, params)) { return rc; }
+    if (!target_host) { return fail(LUMA_E_ARG, "luma_hip_render", "null target"); }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_render", "hipSetDevice failed"); }
+
+    const auto t0 = std::chrono::steady_clock::now();
+    if (int rc = enqueue_render(ctx, params, ctx->d_target, ctx->stream)) { return rc; }
+    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    LUMA_HIP_TRY(hipMemcpy(target_host, ctx->d_target, ctx->band_pixels() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const auto t2 = std::chrono::steady_clock::now();
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        if (int rc = collect_stats(ctx, ctx->stream, stats)) { return rc; }
+        stats->gather_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        stats->total_ms = std::chrono::duration<double, std::milli>(t2 - t0).count();
+    }
+    return LUMA_OK;
+}
+
+int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* target_dev, void* stream,
+                           luma_stats* stats)
+{
+    if (int rc = check_params(ctx, params)) { return rc; }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_render_device", "hipSetDevice failed"); }
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (int rc = enqueue_render(ctx, params, target_dev ? target_dev : ctx->d_target, s)) { return rc; }
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        if (int rc = collect_stats(ctx, s, stats)) { return rc; }
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return LUMA_OK;
+}
+
+int luma_hip_target_device(luma_ctx* ctx, uint32_t** target_dev)
+{
+    if (!ctx || !target_dev) { return fail(LUMA_E_ARG, "luma_hip_target_device", "null argument"); }
+    if (!ctx->have_frame) { return fail(LUMA_E_STATE, "luma_hip_target_device", "luma_hip_set_frame not called"); }
+    *target_dev = ctx->d_target;
+    return LUMA_OK;
+}
+
+int luma_hip_read_accum(luma_ctx* ctx, float* rgb_host)
+{
+    if (!ctx || !rgb_host) { return fail(LUMA_E_ARG, "luma_hip_read_accum", "null argument"); }
+    if (!ctx->have_frame) { return fail(LUMA_E_STATE, "luma_hip_read_accum", "luma_hip_set_frame not called"); }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_read_accum", "hipSetDevice failed"); }
+    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t px = ctx->band_pixels();
+    std::vector<float> planes;
+    try { planes.resize(3 * px); } catch (...) { return fail(LUMA_E_NOMEM, "luma_hip_read_accum", "host allocation failed"); }
+    LUMA_HIP_TRY(hipMemcpy(planes.data(), ctx->d_acc, 3 * px * sizeof(float), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < px; i++) {   // planar on the device, AoS rgb at the boundary (renderer.h:56)
+        rgb_host[3 * i + 0] = planes[i];
+        rgb_host[3 * i + 1] = planes[px + i];
+        rgb_host[3 * i + 2] = planes[2 * px + i];
+    }
+    return LUMA_OK;
+}
+
+int luma_hip_frame_index(luma_ctx* ctx, uint32_t* frame_index)
+{
+    if (!ctx || !frame_index) { return fail(LUMA_E_ARG, "luma_hip_frame_index", "null argument"); }
+    *frame_index = ctx->frame_index;
+    return LUMA_OK;
+}
+
+int luma_hip_generate_rays(luma_ctx* ctx, float* rays_host)
+{
+    if (!ctx || !rays_host) { return fail(LUMA_E_ARG, "luma_hip_generate_rays", "null argument"); }
+    if (!ctx->have_camera || !ctx->have_frame) {
+        return fail(LUMA_E_STATE, "luma_hip_generate_rays", "camera and frame must be set");
+    }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_generate_rays", "hipSetDevice failed"); }
+    const size_t bytes = ctx->band_pixels() * 3 * sizeof(float);
+    float* d_rays = nullptr;
+    LUMA_HIP_TRY(hipMalloc(&d_rays, bytes));
+    const luma::RenderArgs args = make_args(ctx, nullptr, nullptr);
+    hipError_t e = luma::launch_generate_rays(args, d_rays, ctx->stream);
+    if (e == hipSuccess) { e = hipStreamSynchronize(ctx->stream); }
+    if (e == hipSuccess) { e = hipMemcpy(rays_host, d_rays, bytes, hipMemcpyDeviceToHost); }
+    (void)hipFree(d_rays);
+    if (e != hipSuccess) { return fail(LUMA_E_HIP, "luma_hip_generate_rays", hipGetErrorString(e)); }
+    return LUMA_OK;
+}
+
+int luma_camera_default(float fov_deg, float nearclip, float farclip, uint32_t width, uint32_t height,
+                        luma_camera* out)
+{
+    if (!out || width == 0 || height == 0) { return fail(LUMA_E_ARG, "luma_camera_default", "bad argument"); }
+    luma::camera_default(fov_deg, nearclip, farclip, width, height, out);
+    return LUMA_OK;
+}
+
+int luma_camera_from_pose(float fov_deg, float nearclip, float farclip, uint32_t width, uint32_t height,
+                          const float pos[3], float pitch, float yaw, luma_camera* out)
+{
+    if (!out || !pos || width == 0 || height == 0) { return fail(LUMA_E_ARG, "luma_camera_from_pose", "bad argument"); }
+    luma::camera_from_pose(fov_deg, nearclip, farclip, width, height, pos, pitch, yaw, out);
+    return LUMA_OK;
+}
+
+int luma_scene_default(luma_sphere* out)
+{
+    if (!out) { return fail(LUMA_E_ARG, "luma_scene_default", "null argument"); }
+    luma::scene_default(out);
+    return LUMA_OK;
+}
+
+int luma_scene_synthetic(luma_sphere* out, uint32_t n, uint64_t seed)
+{
+    if (!out && n) { return fail(LUMA_E_ARG, "luma_scene_synthetic", "null argument"); }
+    luma::scene_synthetic(out, n, seed);
+    return LUMA_OK;
+}
+
+}  // extern "C"

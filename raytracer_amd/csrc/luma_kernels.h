@@ -1,0 +1,55 @@
+// luma_kernels.h -- kernel argument block and launcher prototypes shared by
+// luma_kernels.hip (device) and luma_abi.cpp (the C-ABI layer).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace luma {
+
+enum : uint32_t {
+    FLAG_NOISE_OFF       = 1u,
+    FLAG_ORIGIN_FROM_HIT = 2u,
+    FLAG_CLAMP_PACK      = 4u,
+    FLAG_NO_SHOW_DEPTH   = 8u,
+};
+enum : uint32_t { MODE_RAYTRACE = 0, MODE_PATHTRACE = 1 };
+
+// gfx950 has 160 KiB of LDS per CU; keep a little for the compiler.  2 x 16 B per sphere
+// => up to 5056 spheres are scanned from LDS, larger scenes from global memory.
+static constexpr size_t kMaxSceneLdsBytes = 158 * 1024;
+
+// Passed by value as the kernel argument (lands in SGPRs / the kernarg segment).
+struct RenderArgs {
+    // frame geometry: this launch renders rows [row_begin,row_end) of width x height
+    uint32_t width, height, row_begin, row_end;
+    // luma::Options snapshot (arguments.h:35-41)
+    uint32_t bounces, paths, mode, flags, spp;
+    uint32_t frame_index;       // frames accumulated before this launch
+    float    frame_count_last;  // frame_count of the last frame of this launch (renderer.h:53)
+    float    inv_samples;       // 1.f / _options.samples (Renderer.cpp:212)
+    uint32_t key[3];            // counter-RNG keys derived from the seed
+    // camera (camera.h:23-37)
+    float    cam_pos[3];
+    float    proj_inv[16];
+    float    view_inv[16];
+    float    focus_depth;
+    uint32_t show_depth;
+    // scene
+    uint32_t n_spheres;
+    const float4* records;      // [0,n): (camera.pos-centre, c)   [n,2n): (centre, radius)
+    const float4* mat0;         // diffuse rgb, albedo
+    const float2* mat1;         // metallic, roughness
+    // outputs (band-local)
+    float*    acc[3];           // accumulation planes r, g, b
+    uint32_t* target;           // 0x00RRGGBB
+    unsigned long long* counters;  // [0] = rays traced
+};
+
+size_t     scene_lds_bytes(uint32_t n_spheres);
+hipError_t launch_prepare_records(const float* cx, const float* cy, const float* cz, const float* rad,
+                                  uint32_t n, const float pos[3], float4* records, hipStream_t stream);
+hipError_t launch_render(const RenderArgs& args, hipStream_t stream);
+hipError_t launch_generate_rays(const RenderArgs& args, float* rays, hipStream_t stream);
+
+}  // namespace luma

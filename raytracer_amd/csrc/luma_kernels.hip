@@ -1,0 +1,396 @@
+// luma_kernels.hip -- gfx950 (MI355X / CDNA4) kernels for the Luma per-pixel render loop.
+//
+// Replaces the inner loops of Renderer::render_to (Renderer.cpp:366-471) and its callees
+// render_pixel (:289-364), trace_ray (:234-287), indirect_illumination (:182-216),
+// reflect_intersection (:218-232), plus Camera::recompute_rays (Camera.cpp:185-216), all
+// fused into one launch per render call.  Written for wave64 / 4xSIMD32 CUs: FP32 VALU
+// work, no MFMA (the path has no dense contraction).
+//
+// Arithmetic contract (DESIGN.md "Arithmetic contract"): IEEE binary32, RNE, subnormals
+// kept, built with -ffp-contract=off; every fusion is an explicit __builtin_fmaf.  div and
+// sqrt are hipcc's correctly rounded forms (default -fhip-fp32-correctly-rounded-divide-sqrt).
+// The closest-hit scan uses the half-b quadratic (b' = b/2, d' = d/4), which is bit-identical
+// to the reference's b = 2*dot, d = b*b - 4ac form because scaling by powers of two commutes
+// with rounding.
+#include "luma_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <stdint.h>
+
+namespace luma {
+
+#define LUMA_DEV __device__ __forceinline__
+
+struct f3 { float x, y, z; };
+
+LUMA_DEV f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+LUMA_DEV f3 add3(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+LUMA_DEV f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+LUMA_DEV f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+LUMA_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+LUMA_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+LUMA_DEV float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+LUMA_DEV f3 normalize3(f3 a) { float inv = 1.0f / __builtin_sqrtf(dot3(a, a)); return scale3(a, inv); }
+LUMA_DEV f3 fma3(f3 a, float s, f3 c) { return mk3(fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z)); }
+
+// exp() of the contract: Cody-Waite by ln2, degree-5 polynomial, 2^k through the exponent
+// field.  Stands in for std::exp at Renderer.cpp:61 and :427.
+LUMA_DEV float luma_expf(float x)
+{
+    if (!(x >= -87.0f)) { return (x != x) ? x : 0.0f; }
+    if (x > 88.0f) { return __builtin_inff(); }
+    float kf = __builtin_rintf(x * 1.44269504088896341f);
+    float r = fma_(kf, -0.693359375f, x);
+    r = fma_(kf, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fma_(p, r, 1.3981999507e-3f);
+    p = fma_(p, r, 8.3334519073e-3f);
+    p = fma_(p, r, 4.1665795894e-2f);
+    p = fma_(p, r, 1.6666665459e-1f);
+    p = fma_(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float e = fma_(p, r2, r) + 1.0f;
+    int k = (int)kf;
+    float s = __builtin_bit_cast(float, (uint32_t)(k + 127) << 23);
+    return e * s;
+}
+
+// pcg3d (Jarzynski & Olano 2020) over (pixel, sample, slot) ^ keys: the counter RNG.
+struct u3 { uint32_t x, y, z; };
+LUMA_DEV u3 pcg3d(uint32_t x, uint32_t y, uint32_t z)
+{
+    x = x * 1664525u + 1013904223u;
+    y = y * 1664525u + 1013904223u;
+    z = z * 1664525u + 1013904223u;
+    x += y * z; y += z * x; z += x * y;
+    x ^= x >> 16; y ^= y >> 16; z ^= z >> 16;
+    x += y * z; y += z * x; z += x * y;
+    u3 r; r.x = x; r.y = y; r.z = z; return r;
+}
+LUMA_DEV float u01(uint32_t bits) { return (float)(bits >> 8) * 5.9604644775390625e-8f; }
+
+// fx::Random::vec3(lo, hi) at Renderer.cpp:118 and :226.
+LUMA_DEV f3 rng_vec3(const RenderArgs& A, uint32_t pixel, uint32_t sample, uint32_t slot, float lo, float hi)
+{
+    u3 h = pcg3d(pixel ^ A.key[0], sample ^ A.key[1], slot ^ A.key[2]);
+    float w = hi - lo;
+    return mk3(fma_(u01(h.x), w, lo), fma_(u01(h.y), w, lo), fma_(u01(h.z), w, lo));
+}
+
+// ::lerp, Renderer.cpp:72-83
+LUMA_DEV f3 color_lerp(f3 c1, f3 c2, float t)
+{
+    float t1 = 1.0f - t;
+    return mk3(fma_(c2.x, t, c1.x * t1), fma_(c2.y, t, c1.y * t1), fma_(c2.z, t, c1.z * t1));
+}
+
+// fx::apply(mat4, vec4): m[col][row], left-to-right fused chain (Camera.cpp:203, :212).
+LUMA_DEV void apply4(const float* m, float v0, float v1, float v2, float v3, float out[4])
+{
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        out[r] = fma_(m[12 + r], v3, fma_(m[8 + r], v2, fma_(m[4 + r], v1, m[r] * v0)));
+    }
+}
+
+// One entry of Camera::recompute_rays, Camera.cpp:193-213, in registers.
+LUMA_DEV f3 camera_ray(const RenderArgs& A, uint32_t x, uint32_t y)
+{
+    float cx = (float)x / (float)A.width;
+    float cy = (float)y / (float)A.height;
+    cx = cx * 2.f - 1.f;
+    cy = cy * 2.f - 1.f;
+    float target[4];
+    apply4(A.proj_inv, cx, cy, 1.f, 1.f, target);
+    const float scalar = 1.0f / target[3];
+    f3 n = normalize3(scale3(mk3(target[0], target[1], target[2]), scalar));
+    float ray[4];
+    apply4(A.view_inv, n.x, n.y, n.z, 0.f, ray);
+    return mk3(ray[0], ray[1], ray[2]);
+}
+
+// Closest-hit linear scan, Renderer::trace_ray (Renderer.cpp:234-287), over records staged
+// in LDS.  Sphere index is wave-uniform, so every ds_read_b128 is a broadcast.
+//   CAM_ORIGIN: the ray starts at camera.pos (every primary / bounce ray in the reference,
+//   Renderer.cpp:303,:416), so diff = camera.pos - centre and c = |diff|^2 - r^2 are
+//   per-sphere constants precomputed into `rec` = (diff.xyz, c).
+//   otherwise: `rec` = (centre.xyz, radius) and diff, c are formed per test (:244-248).
+// Returns the winning index (or -1) and t; hit point / normal are formed by the caller for
+// the winner only (the reference normalises every candidate, :264; same values).
+template <bool CAM_ORIGIN>
+LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin, f3 dir, float& t_out)
+{
+    const float a = dot3(dir, dir);                              // :246 (hoisted: loop invariant)
+    float best_t = FLT_MAX;
+    int best = -1;
+    for (uint32_t i = 0; i < n; i++) {
+        const float4 s = rec[i];
+        float b, c;
+        if (CAM_ORIGIN) {
+            b = dot3(mk3(s.x, s.y, s.z), dir);                   // :247 (half of it)
+            c = s.w;
+        } else {
+            f3 diff = sub3(origin, mk3(s.x, s.y, s.z));          // :244
+            b = dot3(diff, dir);
+            c = fma_(-s.w, s.w, dot3(diff, diff));               // :248
+        }
+        const float d = fma_(b, b, -(a * c));                    // :251 (quarter of it)
+        if (d > 0.0f) {                                          // :253
+            const float t = (-b - __builtin_sqrtf(d)) / a;       // :255
+            if (t > 0.0f && t < best_t) {                        // :258, :266
+                best_t = t;
+                best = (int)i;
+            }
+        }
+    }
+    t_out = best_t;
+    return best;
+}
+
+struct Hit { f3 pos, normal; };
+
+LUMA_DEV Hit finish_hit(const float4* __restrict__ rec_gen, int idx, f3 origin, f3 dir, float t)
+{
+    const float4 s = rec_gen[idx];
+    Hit h;
+    h.pos = fma3(dir, t, origin);                                // :260-261
+    h.normal = normalize3(sub3(h.pos, mk3(s.x, s.y, s.z)));      // :263-264
+    return h;
+}
+
+// Wave-level sum of a per-lane counter, one atomic per wave.
+LUMA_DEV void wave_add_u64(unsigned long long* dst, uint32_t v)
+{
+    unsigned long long s = v;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && s != 0) { atomicAdd(dst, s); }
+}
+
+// ---------------------------------------------------------------------------------
+// The fused render kernel.  One thread per pixel; a wave covers a TILE_W x (64/TILE_W)
+// pixel tile; a 256-thread workgroup covers 2x2 such tiles.  The spp loop runs in
+// registers: one read-modify-write of the accumulation planes and one coalesced store of
+// the packed pixel per launch.
+// ---------------------------------------------------------------------------------
+template <int TILE_W, bool LDS_SCENE>
+__global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
+{
+    extern __shared__ float4 lds_rec[];   // [0,n): camera-origin records; [n,2n): general records
+
+    const uint32_t n = A.n_spheres;
+    const float4* rec_cam;
+    const float4* rec_gen;
+    if (LDS_SCENE) {
+        // Stage both record arrays global -> LDS, 16 B per lane, coalesced.
+        for (uint32_t i = threadIdx.x; i < 2u * n; i += blockDim.x) {
+            lds_rec[i] = A.records[i];
+        }
+        __syncthreads();
+        rec_cam = lds_rec;
+        rec_gen = lds_rec + n;
+    } else {
+        rec_cam = A.records;
+        rec_gen = A.records + n;
+    }
+
+    // lane -> pixel inside the wave tile; wave -> tile inside the workgroup (2 x 2)
+    constexpr int TILE_H = 64 / TILE_W;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * (2 * TILE_W) + (wave & 1u) * TILE_W + (lane % TILE_W);
+    const uint32_t yl = blockIdx.y * (2 * TILE_H) + (wave >> 1) * TILE_H + (lane / TILE_W);
+    const uint32_t y = A.row_begin + yl;
+    const bool live = (x < A.width) && (y < A.row_end);
+
+    uint32_t nrays = 0;
+    if (live) {
+        const uint32_t pixel = y * A.width + x;                  // global index: RNG is band independent (:399)
+        const uint32_t local = yl * A.width + x;                 // index into the band's planes
+        const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
+        const bool noise_off = (A.flags & FLAG_NOISE_OFF) != 0;
+        const bool from_hit = (A.flags & FLAG_ORIGIN_FROM_HIT) != 0;
+        const uint32_t slots = 2u + A.paths;
+
+        const f3 dir0 = camera_ray(A, x, y);                     // camera.rays[index], :413
+
+        // DOF pre-pass, :416-432.  Noise free, so it is the same for every frame of the call.
+        float t0;
+        const int h0 = scan_spheres<true>(rec_cam, n, campos, dir0, t0);
+        nrays++;
+        const float depth = (h0 >= 0) ? t0 : FLT_MAX;            // :419-423
+        const float dd = depth - A.focus_depth;                  // :425
+        const float x2 = dd * dd, x4 = x2 * x2, x8 = x4 * x4, x10 = x8 * x2;
+        const float focus = 1.0f - luma_expf(-x10);              // :427
+        const float blur = fma_(focus, 4.5f, 0.5f);              // :429-432
+        const bool brighten = A.show_depth && (focus < .5f);     // :448-450
+
+        float acc_r = A.acc[0][local], acc_g = A.acc[1][local], acc_b = A.acc[2][local];
+
+        for (uint32_t s = 0; s < A.spp; s++) {
+            const uint32_t sample = A.frame_index + s;
+            f3 direct = mk3(0.f, 0.f, 0.f);
+            f3 dir = dir0;                                       // :293
+            f3 origin = campos;                                  // :294, :303
+
+            for (uint32_t bounce = 0; bounce < A.bounces; bounce++) {   // :300
+                const uint32_t slot = bounce * slots;
+                f3 nz = mk3(0.f, 0.f, 0.f);
+                if (!noise_off) { nz = rng_vec3(A, pixel, sample, slot, -blur, blur); }  // :118
+                const f3 dn = add3(dir, nz);                     // :119, :302
+
+                float t;
+                int idx;
+                if (from_hit && bounce > 0) { idx = scan_spheres<false>(rec_gen, n, origin, dn, t); }
+                else                        { idx = scan_spheres<true>(rec_cam, n, origin, dn, t); }   // :304
+                nrays++;
+
+                if (idx < 0) {                                   // :306-319
+                    const float clamped = __builtin_fminf(__builtin_fmaxf(dn.y, -1.f), 1.f);
+                    const float adjusted = (clamped + 1.f) * .5f;
+                    direct = add3(direct, color_lerp(mk3(.529f, .808f, .922f), mk3(.106f, .275f, .711f), adjusted));
+                    break;
+                }
+
+                const Hit hit = finish_hit(rec_gen, idx, origin, dn, t);
+                const float4 m0 = A.mat0[idx];                   // diffuse rgb, albedo
+                const float2 m1 = A.mat1[idx];                   // metallic, roughness
+                const f3 diffuse = mk3(m0.x, m0.y, m0.z);
+                const float cos_theta = dot3(neg3(dn), hit.normal);   // :331-332
+
+                if (cos_theta >= 0.0f) {                         // :334
+                    f3 indirect = mk3(0.f, 0.f, 0.f);
+                    if (m0.w > 0.0f) {                           // :337
+                        if (A.mode == MODE_PATHTRACE) {          // :187
+                            for (uint32_t p = 0; p < A.paths; p++) {   // :192
+                                f3 d = normalize3(rng_vec3(A, pixel, sample, slot + 2u + p, -1.0f, 1.0f));  // :194
+                                if (dot3(d, hit.normal) < 0.0f) { d = neg3(d); }   // :197-200
+                                const f3 nd = add3(hit.normal, d);     // :202
+                                float tc;
+                                const int ci = scan_spheres<false>(rec_gen, n, hit.pos, nd, tc);   // :204
+                                nrays++;
+                                if (ci >= 0) {                   // :206-209
+                                    const float4 cm = A.mat0[ci];
+                                    indirect = add3(indirect, mk3(cm.x, cm.y, cm.z));
+                                }
+                            }
+                        }
+                        indirect = scale3(indirect, A.inv_samples);    // :212-213
+                        indirect = scale3(indirect, m0.w);       // :340
+                    }
+                    const float value = (cos_theta + 1.f) * .5f; // :343
+                    const float scalar = value * (1.f - m1.x);   // :345
+                    const f3 capture = color_lerp(diffuse, indirect, 1.f - scalar);   // :346
+                    direct = fma3(capture, scalar * .8f, direct);    // :347-349
+                }
+
+                if (m1.x == 0.0f) { break; }                     // :353-357
+
+                f3 rn = mk3(0.f, 0.f, 0.f);
+                if (!noise_off) {
+                    const float gain = .2f * m1.y;               // :225
+                    rn = rng_vec3(A, pixel, sample, slot + 1u, -gain, gain);   // :226
+                }
+                const f3 nrm = add3(hit.normal, rn);             // :227
+                const float k = 2.0f * dot3(dn, nrm);            // fx::reflect, :229
+                dir = fma3(nrm, -k, dn);                         // :359
+                if (from_hit) { origin = fma3(hit.normal, .001f, hit.pos); }   // :221-222
+            }
+
+            f3 result = mk3(1.0f - luma_expf(-direct.x), 1.0f - luma_expf(-direct.y),
+                            1.0f - luma_expf(-direct.z));        // :362, :57-70
+            if (brighten) { result = scale3(result, 1.2f); }     // :452
+            acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
+        }
+
+        A.acc[0][local] = acc_r; A.acc[1][local] = acc_g; A.acc[2][local] = acc_b;
+
+        const float inv = 1.0f / A.frame_count_last;             // :460
+        int r = (int)((acc_r * inv) * 255.0f);                   // ::RGB, :44-55
+        int g = (int)((acc_g * inv) * 255.0f);
+        int b = (int)((acc_b * inv) * 255.0f);
+        if (A.flags & FLAG_CLAMP_PACK) {
+            r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
+        }
+        A.target[local] = ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;   // :461
+    }
+
+    wave_add_u64(A.counters, nrays);
+}
+
+// Per-sphere records for the scan, rebuilt when the scene or the camera position changes:
+// records[i]     = (camera.pos - centre, |camera.pos - centre|^2 - r^2)   (Renderer.cpp:244,:248)
+// records[n + i] = (centre, radius)
+__global__ void prepare_records_kernel(const float* __restrict__ cx, const float* __restrict__ cy,
+                                       const float* __restrict__ cz, const float* __restrict__ rad,
+                                       uint32_t n, float px, float py, float pz, float4* __restrict__ records)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) { return; }
+    const f3 c = mk3(cx[i], cy[i], cz[i]);
+    const float r = rad[i];
+    const f3 diff = sub3(mk3(px, py, pz), c);
+    records[i] = make_float4(diff.x, diff.y, diff.z, fma_(-r, r, dot3(diff, diff)));
+    records[n + i] = make_float4(c.x, c.y, c.z, r);
+}
+
+// Camera::recompute_rays (Camera.cpp:185-216) as a table, for read-back / parity only.
+__global__ void generate_rays_kernel(const RenderArgs A, float* __restrict__ rays)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t yl = blockIdx.y;
+    const uint32_t y = A.row_begin + yl;
+    if (x >= A.width || y >= A.row_end) { return; }
+    const f3 d = camera_ray(A, x, y);
+    float* o = rays + 3 * ((size_t)yl * A.width + x);
+    o[0] = d.x; o[1] = d.y; o[2] = d.z;
+}
+
+// ---------------------------------------------------------------------------------
+// Launchers (host).  Shapes are validated by the C-ABI layer before these are called.
+// ---------------------------------------------------------------------------------
+static constexpr int kTileW = 16;
+
+size_t scene_lds_bytes(uint32_t n_spheres) { return (size_t)n_spheres * 2u * sizeof(float4); }
+
+hipError_t launch_prepare_records(const float* cx, const float* cy, const float* cz, const float* rad,
+                                  uint32_t n, const float pos[3], float4* records, hipStream_t stream)
+{
+    if (n == 0) { return hipSuccess; }
+    const uint32_t threads = 256, blocks = (n + threads - 1) / threads;
+    hipLaunchKernelGGL(prepare_records_kernel, dim3(blocks), dim3(threads), 0, stream,
+                       cx, cy, cz, rad, n, pos[0], pos[1], pos[2], records);
+    return hipGetLastError();
+}
+
+hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
+{
+    constexpr int tile_h = 64 / kTileW;
+    const uint32_t rows = args.row_end - args.row_begin;
+    const dim3 grid((args.width + 2 * kTileW - 1) / (2 * kTileW), (rows + 2 * tile_h - 1) / (2 * tile_h));
+    const size_t lds = scene_lds_bytes(args.n_spheres);
+    if (lds <= kMaxSceneLdsBytes) {
+        auto k = render_kernel<kTileW, true>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) { return e; }
+        }
+        hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, args);
+    } else {
+        hipLaunchKernelGGL((render_kernel<kTileW, false>), grid, dim3(256), 0, stream, args);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_generate_rays(const RenderArgs& args, float* rays, hipStream_t stream)
+{
+    const uint32_t rows = args.row_end - args.row_begin;
+    const dim3 grid((args.width + 255) / 256, rows);
+    hipLaunchKernelGGL(generate_rays_kernel, grid, dim3(256), 0, stream, args, rays);
+    return hipGetLastError();
+}
+
+}  // namespace luma
