@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s and frame ms of the Luma render loop on MI355X.
+
+Workload (BASELINE.json configs[2], the 1920x1080 config the metric is quoted on):
+reference default 5-sphere scene, 1920x1080, 64 spp accumulated per step, 5 bounces,
+pathtrace, paths=1, counter RNG seed 0x4C554D41.  One "step" = one luma_hip_render_device
+call (64 frames of Renderer::render_to fused in one launch) with the accumulation planes
+and the packed frame resident in HBM.  With N ranks the same frame is split into N scanline
+bands (strong scaling) and the bands are gathered on rank 0 over RCCL inside the timed step.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP, BOUNCES, PATHS, SAMPLES, SEED = 1920, 1080, 64, 5, 1, 1, 0x4C554D41
+FLOP_PER_TEST, FLOP_PER_RAY = 17.0, 64.0          # SURVEY.md 8d / BASELINE.md section 5
+PEAK_FP32_VALU_TFLOPS = 157.3                     # MI355X_MICROARCH.md, "Peak FP32 (vector)"
+
+
+def cpu_baseline(seconds_target=12.0):
+    """The CPU oracle (a port: the reference itself cannot be built) on ONE host core, the
+    reference's execution model (Renderer.cpp:392), on a bounded sample of the same
+    workload: 4-row groups spread evenly over the 1080 rows, all 64 spp."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_binding as ob
+    cam, scene = ob.camera(WIDTH, HEIGHT), ob.default_scene()
+    p = ob.make_params(WIDTH, HEIGHT, spp=SPP, bounces=BOUNCES, paths=PATHS, samples=SAMPLES, mode=1, seed=SEED)
+    r = ob.Renderer(scene, cam, WIDTH, HEIGHT)
+    groups = list(range(0, HEIGHT, 8))             # 135 groups of 4 rows
+    t0 = time.perf_counter()
+    rows = 0
+    for y0 in groups:
+        r.render(p, rows=(y0, y0 + 4))
+        rows += 4
+        if time.perf_counter() - t0 > seconds_target:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": r.stats.rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+            "sample": f"{rows} of {HEIGHT} rows (4-row groups every 8 rows, time-capped) x {WIDTH} px x {SPP} spp, "
+                      f"{r.stats.rays} rays in {dt:.2f} s",
+            "msamples_per_s": rows * WIDTH * SPP / dt / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch                                   # before abi.lib(): one shared HIP runtime
+    import torch.distributed as dist
+    from raytracer_amd import abi, bands
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    y0, y1 = bands.band_rows(HEIGHT, world, rank)
+    ctx = abi.Context(local)
+    ctx.set_scene(abi.default_scene())
+    ctx.set_camera(abi.default_camera(WIDTH, HEIGHT))
+    ctx.set_frame(WIDTH, HEIGHT, y0, y1)
+    params = abi.make_params(WIDTH, HEIGHT, spp=SPP, bounces=BOUNCES, paths=PATHS, samples=SAMPLES,
+                             mode=abi.MODE_PATHTRACE, flags=0, seed=SEED)
+    band = torch.empty((y1 - y0, WIDTH), dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream(device=dev)          # a real (non-null) stream: kernels, gather and events share it
+    torch.cuda.set_stream(stream)
+
+    def step():
+        ctx.render_device(params, band.data_ptr(), stream.cuda_stream)
+        return bands.gather_frame(band, HEIGHT, WIDTH, rank, world)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    ctx.render_device(params, band.data_ptr(), stream.cuda_stream, want_stats=True)   # drain the ray counter
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+
+    # kernel-only leg: K back-to-back launches between two HIP events on the launch stream
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ctx.render_device(params, band.data_ptr(), stream.cuda_stream, want_stats=True)   # counts timed steps
+    fence()
+    ev0.record(stream)
+    for _ in range(a.steps):
+        ctx.render_device(params, band.data_ptr(), stream.cuda_stream)
+    ev1.record(stream)
+    st = ctx.render_device(params, band.data_ptr(), stream.cuda_stream, want_stats=True)
+    torch.cuda.synchronize()
+    kernel_ms = ev0.elapsed_time(ev1) / a.steps
+    rays_per_launch = st.rays / (a.steps + 1)      # a.steps timed launches + the stats launch itself
+    tests_per_launch = st.sphere_tests / (a.steps + 1)
+
+    t = torch.tensor([dt, rays_per_launch, tests_per_launch, kernel_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, kernel_ms = float(tmax[0]), float(tmax[3])
+        rays_per_step, tests_per_step = float(tsum[1]), float(tsum[2])
+    else:
+        rays_per_step, tests_per_step = rays_per_launch, tests_per_launch
+
+    if rank == 0:
+        ms_per_step = dt / a.steps * 1e3
+        value = rays_per_step * a.steps / dt / 1e6
+        flop = FLOP_PER_TEST * tests_per_launch + FLOP_PER_RAY * rays_per_launch   # rank 0's launch
+        achieved = flop / (kernel_ms * 1e-3) / 1e12
+        out = {
+            "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"default 5-sphere scene {WIDTH}x{HEIGHT}, {SPP} spp/step, {BOUNCES} bounces, "
+                                   f"pathtrace paths={PATHS}, seed 0x{SEED:08X} (BASELINE configs[2])",
+                       "parallelism": f"{world} scanline band(s), RCCL gather to rank 0"},
+            "frame_ms": ms_per_step,
+            "msamples_per_s": WIDTH * HEIGHT * SPP * a.steps / dt / 1e6,
+            "rays_per_step": rays_per_step,
+            "kernel_ms": kernel_ms,
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "kernel": "luma::render_kernel", "flop_model": "17*sphere_tests + 64*rays (SURVEY 8d)"},
+        }
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

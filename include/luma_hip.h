@@ -77,6 +77,9 @@ typedef struct {
     double   kernel_ms;     /* render kernel(s), HIP events on the context's stream */
     double   gather_ms;     /* device->host (and inter-device) copy of the frame */
     double   total_ms;      /* wall clock of the call */
+    /* Work counters cover every render call on the context since the previous call that
+     * returned a luma_stats (so a run of stats-less luma_hip_render_device calls can be
+     * totalled by the last one); the times are those of this call alone. */
     uint64_t rays;          /* trace_ray invocations executed (Renderer.cpp:234) */
     uint64_t sphere_tests;  /* ray-sphere tests executed (loop at Renderer.cpp:242) */
 } luma_stats;

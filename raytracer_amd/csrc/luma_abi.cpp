@@ -90,8 +90,9 @@ struct luma_ctx {
     uint32_t frame_index = 0;
     bool have_frame = false;
 
-    unsigned long long* d_counters = nullptr;  // [0] rays
+    unsigned long long* d_counters = nullptr;  // [0] rays traced since luma_hip_create (never reset)
     unsigned long long* h_counters = nullptr;  // pinned
+    unsigned long long rays_reported = 0;      // part of d_counters[0] already handed out in a luma_stats
 
     size_t band_pixels() const { return static_cast<size_t>(row_end - row_begin) * width; }
 };
@@ -172,7 +173,6 @@ int refresh_records(luma_ctx* ctx, hipStream_t stream)
 int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hipStream_t stream)
 {
     if (int rc = refresh_records(ctx, stream)) { return rc; }
-    LUMA_HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long), stream));
     const luma::RenderArgs args = make_args(ctx, p, target_dev);
     LUMA_HIP_TRY(hipEventRecord(ctx->ev_begin, stream));
     LUMA_HIP_TRY(luma::launch_render(args, stream));
@@ -189,7 +189,8 @@ int collect_stats(luma_ctx* ctx, hipStream_t stream, luma_stats* stats)
     float ms = 0.f;
     LUMA_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     stats->kernel_ms = ms;
-    stats->rays = ctx->h_counters[0];
+    stats->rays = ctx->h_counters[0] - ctx->rays_reported;   // since the previous luma_stats
+    ctx->rays_reported = ctx->h_counters[0];
     stats->sphere_tests = stats->rays * ctx->n_spheres;   // every ray scans every sphere (Renderer.cpp:242)
     return LUMA_OK;
 }
@@ -242,6 +243,7 @@ int luma_hip_create(luma_ctx** out, int device_id)
     if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) { return bail(e, "hipEventCreate"); }
     if ((e = hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long))) != hipSuccess) { return bail(e, "hipMalloc(counters)"); }
     if ((e = hipHostMalloc(&ctx->h_counters, 2 * sizeof(unsigned long long))) != hipSuccess) { return bail(e, "hipHostMalloc(counters)"); }
+    if ((e = hipMemset(ctx->d_counters, 0, 2 * sizeof(unsigned long long))) != hipSuccess) { return bail(e, "hipMemset(counters)"); }
     *out = ctx;
     return LUMA_OK;
 }

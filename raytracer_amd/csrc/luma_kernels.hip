@@ -136,7 +136,8 @@ LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin,
             c = fma_(-s.w, s.w, dot3(diff, diff));               // :248
         }
         const float d = fma_(b, b, -(a * c));                    // :251 (quarter of it)
-        if (d > 0.0f) {                                          // :253
+        // b >= 0 gives -b - sqrt(d) < 0, i.e. t <= 0 (:258 rejects it): skip the sqrt and divide.
+        if (d > 0.0f && b < 0.0f) {                              // :253
             const float t = (-b - __builtin_sqrtf(d)) / a;       // :255
             if (t > 0.0f && t < best_t) {                        // :258, :266
                 best_t = t;
@@ -172,11 +173,19 @@ LUMA_DEV void wave_add_u64(unsigned long long* dst, uint32_t v)
 
 // ---------------------------------------------------------------------------------
 // The fused render kernel.  One thread per pixel; a wave covers a TILE_W x (64/TILE_W)
-// pixel tile; a 256-thread workgroup covers 2x2 such tiles.  The spp loop runs in
-// registers: one read-modify-write of the accumulation planes and one coalesced store of
-// the packed pixel per launch.
+// pixel tile; a 256-thread workgroup covers 2x2 such tiles.
+//
+// The reference nests  frames > pixels > bounces  (Renderer.cpp:393-395, :300).  Bounce
+// counts differ per sample (a miss ends the path, :318), so a literal nest leaves most of a
+// wave idle while its longest path finishes.  Here each lane runs ONE flat loop over
+// (sample, bounce) steps of its own pixel: a lane whose path ends adds the sample to its
+// accumulator and starts its next sample in the same iteration, so lanes only idle at the
+// very end of the launch.  Per pixel the samples are still added in frame order, which
+// keeps the sum bit-identical to frame-by-frame accumulation (:457-458).  The spp loop
+// lives in registers: one read-modify-write of the accumulation planes and one coalesced
+// store of the packed pixel per launch.
 // ---------------------------------------------------------------------------------
-template <int TILE_W, bool LDS_SCENE>
+template <int TILE_W, bool LDS_SCENE, bool NOISE, bool FROM_HIT>
 __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 {
     extern __shared__ float4 lds_rec[];   // [0,n): camera-origin records; [n,2n): general records
@@ -210,9 +219,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         const uint32_t pixel = y * A.width + x;                  // global index: RNG is band independent (:399)
         const uint32_t local = yl * A.width + x;                 // index into the band's planes
         const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
-        const bool noise_off = (A.flags & FLAG_NOISE_OFF) != 0;
-        const bool from_hit = (A.flags & FLAG_ORIGIN_FROM_HIT) != 0;
         const uint32_t slots = 2u + A.paths;
+        const bool pathtrace = A.mode == MODE_PATHTRACE;
 
         const f3 dir0 = camera_ray(A, x, y);                     // camera.rays[index], :413
 
@@ -225,35 +233,39 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         const float x2 = dd * dd, x4 = x2 * x2, x8 = x4 * x4, x10 = x8 * x2;
         const float focus = 1.0f - luma_expf(-x10);              // :427
         const float blur = fma_(focus, 4.5f, 0.5f);              // :429-432
-        const bool brighten = A.show_depth && (focus < .5f);     // :448-450
+        const float gainf = (A.show_depth && (focus < .5f)) ? 1.2f : 1.0f;   // :448-452
 
         float acc_r = A.acc[0][local], acc_g = A.acc[1][local], acc_b = A.acc[2][local];
 
-        for (uint32_t s = 0; s < A.spp; s++) {
+        // per-lane path state
+        uint32_t s = 0, bounce = 0;
+        f3 direct = mk3(0.f, 0.f, 0.f);
+        f3 dir = dir0;                                           // :293
+        f3 origin = campos;                                      // :294, :303
+
+        // bounces == 0: the loop at :300 never runs, every sample adds tonemap(0) * gain = +0.
+        const uint32_t spp = A.bounces ? A.spp : 0u;
+
+        while (s < spp) {
             const uint32_t sample = A.frame_index + s;
-            f3 direct = mk3(0.f, 0.f, 0.f);
-            f3 dir = dir0;                                       // :293
-            f3 origin = campos;                                  // :294, :303
+            const uint32_t slot = bounce * slots;
+            f3 dn = dir;
+            if (NOISE) { dn = add3(dir, rng_vec3(A, pixel, sample, slot, -blur, blur)); }   // :118-119, :302
+            else       { dn = add3(dir, mk3(0.f, 0.f, 0.f)); }
 
-            for (uint32_t bounce = 0; bounce < A.bounces; bounce++) {   // :300
-                const uint32_t slot = bounce * slots;
-                f3 nz = mk3(0.f, 0.f, 0.f);
-                if (!noise_off) { nz = rng_vec3(A, pixel, sample, slot, -blur, blur); }  // :118
-                const f3 dn = add3(dir, nz);                     // :119, :302
+            float t;
+            int idx;
+            if (FROM_HIT && bounce > 0) { idx = scan_spheres<false>(rec_gen, n, origin, dn, t); }
+            else                        { idx = scan_spheres<true>(rec_cam, n, origin, dn, t); }   // :304
+            nrays++;
 
-                float t;
-                int idx;
-                if (from_hit && bounce > 0) { idx = scan_spheres<false>(rec_gen, n, origin, dn, t); }
-                else                        { idx = scan_spheres<true>(rec_cam, n, origin, dn, t); }   // :304
-                nrays++;
-
-                if (idx < 0) {                                   // :306-319
-                    const float clamped = __builtin_fminf(__builtin_fmaxf(dn.y, -1.f), 1.f);
-                    const float adjusted = (clamped + 1.f) * .5f;
-                    direct = add3(direct, color_lerp(mk3(.529f, .808f, .922f), mk3(.106f, .275f, .711f), adjusted));
-                    break;
-                }
-
+            bool path_ends;
+            if (idx < 0) {                                       // :306-319
+                const float clamped = __builtin_fminf(__builtin_fmaxf(dn.y, -1.f), 1.f);
+                const float adjusted = (clamped + 1.f) * .5f;
+                direct = add3(direct, color_lerp(mk3(.529f, .808f, .922f), mk3(.106f, .275f, .711f), adjusted));
+                path_ends = true;
+            } else {
                 const Hit hit = finish_hit(rec_gen, idx, origin, dn, t);
                 const float4 m0 = A.mat0[idx];                   // diffuse rgb, albedo
                 const float2 m1 = A.mat1[idx];                   // metallic, roughness
@@ -263,7 +275,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 if (cos_theta >= 0.0f) {                         // :334
                     f3 indirect = mk3(0.f, 0.f, 0.f);
                     if (m0.w > 0.0f) {                           // :337
-                        if (A.mode == MODE_PATHTRACE) {          // :187
+                        if (pathtrace) {                         // :187
                             for (uint32_t p = 0; p < A.paths; p++) {   // :192
                                 f3 d = normalize3(rng_vec3(A, pixel, sample, slot + 2u + p, -1.0f, 1.0f));  // :194
                                 if (dot3(d, hit.normal) < 0.0f) { d = neg3(d); }   // :197-200
@@ -286,23 +298,33 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                     direct = fma3(capture, scalar * .8f, direct);    // :347-349
                 }
 
-                if (m1.x == 0.0f) { break; }                     // :353-357
-
-                f3 rn = mk3(0.f, 0.f, 0.f);
-                if (!noise_off) {
-                    const float gain = .2f * m1.y;               // :225
-                    rn = rng_vec3(A, pixel, sample, slot + 1u, -gain, gain);   // :226
+                bounce++;
+                path_ends = (m1.x == 0.0f) || (bounce == A.bounces);   // :353-357, :300
+                if (!path_ends) {
+                    f3 nrm = hit.normal;
+                    if (NOISE) {
+                        const float gain = .2f * m1.y;           // :225
+                        nrm = add3(nrm, rng_vec3(A, pixel, sample, slot + 1u, -gain, gain));   // :226-227
+                    } else {
+                        nrm = add3(nrm, mk3(0.f, 0.f, 0.f));
+                    }
+                    const float k = 2.0f * dot3(dn, nrm);        // fx::reflect, :229
+                    dir = fma3(nrm, -k, dn);                     // :359
+                    if (FROM_HIT) { origin = fma3(hit.normal, .001f, hit.pos); }   // :221-222
                 }
-                const f3 nrm = add3(hit.normal, rn);             // :227
-                const float k = 2.0f * dot3(dn, nrm);            // fx::reflect, :229
-                dir = fma3(nrm, -k, dn);                         // :359
-                if (from_hit) { origin = fma3(hit.normal, .001f, hit.pos); }   // :221-222
             }
 
-            f3 result = mk3(1.0f - luma_expf(-direct.x), 1.0f - luma_expf(-direct.y),
-                            1.0f - luma_expf(-direct.z));        // :362, :57-70
-            if (brighten) { result = scale3(result, 1.2f); }     // :452
-            acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
+            if (path_ends) {
+                f3 result = mk3(1.0f - luma_expf(-direct.x), 1.0f - luma_expf(-direct.y),
+                                1.0f - luma_expf(-direct.z));    // :362, :57-70
+                if (gainf != 1.0f) { result = scale3(result, gainf); }   // :452
+                acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
+                s++;
+                bounce = 0;
+                direct = mk3(0.f, 0.f, 0.f);
+                dir = dir0;
+                origin = campos;
+            }
         }
 
         A.acc[0][local] = acc_r; A.acc[1][local] = acc_g; A.acc[2][local] = acc_b;
@@ -370,18 +392,25 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     constexpr int tile_h = 64 / kTileW;
     const uint32_t rows = args.row_end - args.row_begin;
     const dim3 grid((args.width + 2 * kTileW - 1) / (2 * kTileW), (rows + 2 * tile_h - 1) / (2 * tile_h));
-    const size_t lds = scene_lds_bytes(args.n_spheres);
-    if (lds <= kMaxSceneLdsBytes) {
-        auto k = render_kernel<kTileW, true>;
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) { return e; }
-        }
-        hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, args);
-    } else {
-        hipLaunchKernelGGL((render_kernel<kTileW, false>), grid, dim3(256), 0, stream, args);
+    const size_t scene = scene_lds_bytes(args.n_spheres);
+    const bool in_lds = scene <= kMaxSceneLdsBytes;
+    const size_t lds = in_lds ? scene : 0;
+    const bool noise = !(args.flags & FLAG_NOISE_OFF), from_hit = (args.flags & FLAG_ORIGIN_FROM_HIT) != 0;
+
+    using kernel_t = void (*)(const RenderArgs);
+    static const kernel_t table[2][2][2] = {
+        { { render_kernel<kTileW, false, false, false>, render_kernel<kTileW, false, false, true> },
+          { render_kernel<kTileW, false, true, false>,  render_kernel<kTileW, false, true, true> } },
+        { { render_kernel<kTileW, true, false, false>,  render_kernel<kTileW, true, false, true> },
+          { render_kernel<kTileW, true, true, false>,   render_kernel<kTileW, true, true, true> } },
+    };
+    const kernel_t k = table[in_lds][noise][from_hit];
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { return e; }
     }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, args);
     return hipGetLastError();
 }
 
