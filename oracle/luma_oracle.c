@@ -110,16 +110,17 @@ void lo_seed_keys(uint64_t seed, uint32_t keys[3])
 /* u32 -> [0,1): top 24 bits, exact. */
 static float u01(uint32_t bits) { return (float)(bits >> 8) * 5.9604644775390625e-8f; }
 
-/* fx::Random::vec3(lo, hi) [flux-inferred]: three independent uniforms in [lo,hi). */
+/* fx::Random::vec3(lo, hi) [flux-inferred]: three independent uniforms in [lo,hi):
+ * lo + k * ((hi-lo) * 2^-24) with k the top 24 bits of each hash word, one rounding. */
 void lo_rng_vec3(const uint32_t keys[3], uint32_t pixel, uint32_t sample, uint32_t slot,
                  float lo, float hi, float out[3])
 {
     uint32_t h[3];
     lo_pcg3d(pixel ^ keys[0], sample ^ keys[1], slot ^ keys[2], h);
-    float w = hi - lo;
-    out[0] = FMA(u01(h[0]), w, lo);
-    out[1] = FMA(u01(h[1]), w, lo);
-    out[2] = FMA(u01(h[2]), w, lo);
+    float w = (hi - lo) * 5.9604644775390625e-8f;
+    out[0] = FMA((float)(h[0] >> 8), w, lo);
+    out[1] = FMA((float)(h[1] >> 8), w, lo);
+    out[2] = FMA((float)(h[2] >> 8), w, lo);
 }
 
 /* fx::Random::vec3_sphere() [flux-inferred, low confidence]: normalize(vec3(-1,1)). */

@@ -31,7 +31,24 @@ LUMA_DEV f3 scale3(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 LUMA_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 LUMA_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 LUMA_DEV float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
-LUMA_DEV f3 normalize3(f3 a) { float inv = 1.0f / __builtin_sqrtf(dot3(a, a)); return scale3(a, inv); }
+
+// Correctly rounded sqrt.  hipcc's sqrtf() expansion spends 6 of its 17 VALU instructions on
+// rescaling tiny inputs and on the 0/inf class check; for 2^-96 <= x < 2^96 (every
+// discriminant and squared length on the path) the core of that expansion alone is exact:
+// v_sqrt_f32 is within 1 ulp, and the two residuals pick the neighbour when it is closer.
+LUMA_DEV float sqrt_rn(float x)
+{
+    if (__builtin_expect(!(x >= 0x1p-96f && x < 0x1p96f), 0)) { return __builtin_sqrtf(x); }
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float s_up = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float r_dn = fma_(-s_dn, s, x);
+    const float r_up = fma_(-s_up, s, x);
+    float r = (r_dn <= 0.0f) ? s_dn : s;
+    r = (r_up > 0.0f) ? s_up : r;
+    return r;
+}
+LUMA_DEV f3 normalize3(f3 a) { float inv = 1.0f / sqrt_rn(dot3(a, a)); return scale3(a, inv); }
 LUMA_DEV f3 fma3(f3 a, float s, f3 c) { return mk3(fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z)); }
 
 // exp() of the contract: Cody-Waite by ln2, degree-5 polynomial, 2^k through the exponent
@@ -68,14 +85,13 @@ LUMA_DEV u3 pcg3d(uint32_t x, uint32_t y, uint32_t z)
     x += y * z; y += z * x; z += x * y;
     u3 r; r.x = x; r.y = y; r.z = z; return r;
 }
-LUMA_DEV float u01(uint32_t bits) { return (float)(bits >> 8) * 5.9604644775390625e-8f; }
 
 // fx::Random::vec3(lo, hi) at Renderer.cpp:118 and :226.
 LUMA_DEV f3 rng_vec3(const RenderArgs& A, uint32_t pixel, uint32_t sample, uint32_t slot, float lo, float hi)
 {
     u3 h = pcg3d(pixel ^ A.key[0], sample ^ A.key[1], slot ^ A.key[2]);
-    float w = hi - lo;
-    return mk3(fma_(u01(h.x), w, lo), fma_(u01(h.y), w, lo), fma_(u01(h.z), w, lo));
+    const float w = (hi - lo) * 5.9604644775390625e-8f;          // (hi-lo) * 2^-24
+    return mk3(fma_((float)(h.x >> 8), w, lo), fma_((float)(h.y >> 8), w, lo), fma_((float)(h.z >> 8), w, lo));
 }
 
 // ::lerp, Renderer.cpp:72-83
@@ -122,7 +138,13 @@ template <bool CAM_ORIGIN>
 LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin, f3 dir, float& t_out)
 {
     const float a = dot3(dir, dir);                              // :246 (hoisted: loop invariant)
-    float best_t = FLT_MAX;
+    // t = num / a with num = -b - sqrt(d).  a > 0 is the same for every sphere, so candidates
+    // are ordered by num and the divide is done once, for the winner.  Rounding can make two
+    // different num give the same t (the reference then keeps the earlier sphere, :266), so
+    // when num is within 2^-22 of the best, or so small that num/a could flush to 0 (:258),
+    // both quotients are formed and compared exactly as the reference does.
+    const bool odd_a = !(a > 1e-30f && a < 1e30f);
+    float best_num = __builtin_inff();
     int best = -1;
     for (uint32_t i = 0; i < n; i++) {
         const float4 s = rec[i];
@@ -136,16 +158,21 @@ LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin,
             c = fma_(-s.w, s.w, dot3(diff, diff));               // :248
         }
         const float d = fma_(b, b, -(a * c));                    // :251 (quarter of it)
-        // b >= 0 gives -b - sqrt(d) < 0, i.e. t <= 0 (:258 rejects it): skip the sqrt and divide.
+        // b >= 0 gives -b - sqrt(d) < 0, i.e. t <= 0 (:258 rejects it): skip the sqrt.
         if (d > 0.0f && b < 0.0f) {                              // :253
-            const float t = (-b - __builtin_sqrtf(d)) / a;       // :255
-            if (t > 0.0f && t < best_t) {                        // :258, :266
-                best_t = t;
-                best = (int)i;
+            const float num = -b - sqrt_rn(d);                   // :255, numerator
+            if (num > 0.0f && num < best_num) {
+                bool take = true;
+                if (__builtin_expect(odd_a || num < 1e-30f || !(num < best_num * 0.99999976f), 0)) {
+                    const float t = num / a;
+                    const float tb = (best < 0) ? FLT_MAX : best_num / a;
+                    take = (t > 0.0f) && (t < tb);               // :258, :266
+                }
+                if (take) { best_num = num; best = (int)i; }
             }
         }
     }
-    t_out = best_t;
+    t_out = (best >= 0) ? best_num / a : FLT_MAX;
     return best;
 }
 
@@ -185,25 +212,34 @@ LUMA_DEV void wave_add_u64(unsigned long long* dst, uint32_t v)
 // lives in registers: one read-modify-write of the accumulation planes and one coalesced
 // store of the packed pixel per launch.
 // ---------------------------------------------------------------------------------
-template <int TILE_W, bool LDS_SCENE, bool NOISE, bool FROM_HIT>
+// Where the scene lives during the launch: scan records (32 B/sphere) and, when they also
+// fit, the material vectors (24 B/sphere) are staged into LDS once per workgroup.
+enum : int { SCENE_GLOBAL = 0, SCENE_LDS_RECORDS = 1, SCENE_LDS_ALL = 2 };
+
+template <int TILE_W, int SCENE, bool NOISE, bool FROM_HIT>
 __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
 {
-    extern __shared__ float4 lds_rec[];   // [0,n): camera-origin records; [n,2n): general records
+    // [0,n): camera-origin records; [n,2n): general records; then mat0[n] (float4), mat1[n] (float2)
+    extern __shared__ float4 lds_rec[];
 
     const uint32_t n = A.n_spheres;
-    const float4* rec_cam;
-    const float4* rec_gen;
-    if (LDS_SCENE) {
-        // Stage both record arrays global -> LDS, 16 B per lane, coalesced.
-        for (uint32_t i = threadIdx.x; i < 2u * n; i += blockDim.x) {
-            lds_rec[i] = A.records[i];
-        }
-        __syncthreads();
+    const float4* rec_cam = A.records;
+    const float4* rec_gen = A.records + n;
+    const float4* mat0 = A.mat0;
+    const float2* mat1 = A.mat1;
+    if (SCENE != SCENE_GLOBAL) {
+        // Stage global -> LDS, 16 B per lane, coalesced.
+        for (uint32_t i = threadIdx.x; i < 2u * n; i += blockDim.x) { lds_rec[i] = A.records[i]; }
         rec_cam = lds_rec;
         rec_gen = lds_rec + n;
-    } else {
-        rec_cam = A.records;
-        rec_gen = A.records + n;
+        if (SCENE == SCENE_LDS_ALL) {
+            float4* l0 = lds_rec + 2u * n;
+            float2* l1 = reinterpret_cast<float2*>(l0 + n);
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { l0[i] = A.mat0[i]; l1[i] = A.mat1[i]; }
+            mat0 = l0;
+            mat1 = l1;
+        }
+        __syncthreads();
     }
 
     // lane -> pixel inside the wave tile; wave -> tile inside the workgroup (2 x 2)
@@ -267,8 +303,8 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                 path_ends = true;
             } else {
                 const Hit hit = finish_hit(rec_gen, idx, origin, dn, t);
-                const float4 m0 = A.mat0[idx];                   // diffuse rgb, albedo
-                const float2 m1 = A.mat1[idx];                   // metallic, roughness
+                const float4 m0 = mat0[idx];                   // diffuse rgb, albedo
+                const float2 m1 = mat1[idx];                   // metallic, roughness
                 const f3 diffuse = mk3(m0.x, m0.y, m0.z);
                 const float cos_theta = dot3(neg3(dn), hit.normal);   // :331-332
 
@@ -284,7 +320,7 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
                                 const int ci = scan_spheres<false>(rec_gen, n, hit.pos, nd, tc);   // :204
                                 nrays++;
                                 if (ci >= 0) {                   // :206-209
-                                    const float4 cm = A.mat0[ci];
+                                    const float4 cm = mat0[ci];
                                     indirect = add3(indirect, mk3(cm.x, cm.y, cm.z));
                                 }
                             }
@@ -392,19 +428,22 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     constexpr int tile_h = 64 / kTileW;
     const uint32_t rows = args.row_end - args.row_begin;
     const dim3 grid((args.width + 2 * kTileW - 1) / (2 * kTileW), (rows + 2 * tile_h - 1) / (2 * tile_h));
-    const size_t scene = scene_lds_bytes(args.n_spheres);
-    const bool in_lds = scene <= kMaxSceneLdsBytes;
-    const size_t lds = in_lds ? scene : 0;
+    const size_t rec_bytes = scene_lds_bytes(args.n_spheres);
+    const size_t all_bytes = rec_bytes + (size_t)args.n_spheres * (sizeof(float4) + sizeof(float2));
+    const int scene = all_bytes <= kMaxSceneLdsBytes ? SCENE_LDS_ALL
+                    : rec_bytes <= kMaxSceneLdsBytes ? SCENE_LDS_RECORDS : SCENE_GLOBAL;
+    const size_t lds = scene == SCENE_LDS_ALL ? all_bytes : scene == SCENE_LDS_RECORDS ? rec_bytes : 0;
     const bool noise = !(args.flags & FLAG_NOISE_OFF), from_hit = (args.flags & FLAG_ORIGIN_FROM_HIT) != 0;
 
     using kernel_t = void (*)(const RenderArgs);
-    static const kernel_t table[2][2][2] = {
-        { { render_kernel<kTileW, false, false, false>, render_kernel<kTileW, false, false, true> },
-          { render_kernel<kTileW, false, true, false>,  render_kernel<kTileW, false, true, true> } },
-        { { render_kernel<kTileW, true, false, false>,  render_kernel<kTileW, true, false, true> },
-          { render_kernel<kTileW, true, true, false>,   render_kernel<kTileW, true, true, true> } },
+#define LUMA_K(S, N, F) render_kernel<kTileW, S, N, F>
+    static const kernel_t table[3][2][2] = {
+        { { LUMA_K(0, false, false), LUMA_K(0, false, true) }, { LUMA_K(0, true, false), LUMA_K(0, true, true) } },
+        { { LUMA_K(1, false, false), LUMA_K(1, false, true) }, { LUMA_K(1, true, false), LUMA_K(1, true, true) } },
+        { { LUMA_K(2, false, false), LUMA_K(2, false, true) }, { LUMA_K(2, true, false), LUMA_K(2, true, true) } },
     };
-    const kernel_t k = table[in_lds][noise][from_hit];
+#undef LUMA_K
+    const kernel_t k = table[scene][noise][from_hit];
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -1,0 +1,73 @@
+"""Host logic of the multi-GPU partition (raytracer_amd/bands.py), on CPU: band arithmetic and a
+world_size-2 gloo run of the gather.  The per-rank renderer here is the oracle, standing in for a
+GPU rank; what is under test is the partition + gather, which is device independent."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from raytracer_amd import bands
+
+
+def test_band_rows_partition():
+    for H in (1080, 2160, 4320, 104, 7):
+        for N in (1, 2, 3, 4, 7, 8):
+            if H < N:
+                continue
+            rows = [bands.band_rows(H, N, r) for r in range(N)]
+            assert rows[0][0] == 0 and rows[-1][1] == H
+            assert all(rows[i][1] == rows[i + 1][0] for i in range(N - 1))
+            sizes = [e - b for b, e in rows]
+            assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+    assert bands.band_rows(1080, 8, 3) == (405, 540)      # 135-row bands
+    assert bands.band_rows(2160, 8, 7) == (1890, 2160)
+    with pytest.raises(ValueError):
+        bands.band_rows(4, 8, 0)
+    with pytest.raises(ValueError):
+        bands.band_rows(100, 2, 2)
+
+
+def _worker(rank, world, port, H, W, q):
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_binding as ob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        y0, y1 = bands.band_rows(H, world, rank)
+        p = ob.make_params(W, H, spp=2, bounces=5, mode=1, seed=0x4C554D41)
+        r = ob.Renderer(ob.default_scene(), ob.camera(W, H), W, H)
+        r.render(p, rows=(y0, y1))
+        band = torch.from_numpy(r.target[y0:y1].astype(np.int64).astype(np.int32).copy())
+        frame = bands.gather_frame(band, H, W, rank, world)
+        if rank == 0:
+            q.put(frame.numpy().astype(np.uint32))
+        else:
+            assert frame is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("H", [36, 37])          # equal bands (gather) and ragged bands (send/recv)
+def test_two_rank_gather_equals_full_frame(H):
+    import torch.multiprocessing as mp
+    import oracle_binding as ob
+    W = 48
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, H, W, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    frame = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full, _, _ = ob.render(ob.default_scene(), ob.camera(W, H), ob.make_params(W, H, spp=2, bounces=5, mode=1, seed=0x4C554D41))
+    assert np.array_equal(frame, full)

@@ -167,6 +167,29 @@ def test_progressive_frames_equal_in_kernel_spp(abi, oracle):
     assert_frames_equal(first, want, "first frame after reset")
 
 
+def test_against_committed_golden_frames(abi):
+    """HIP frames against tests/golden/oracle_frames.npz (made by tests/golden/make_golden.py):
+    parity that does not depend on rebuilding the oracle on the GPU box."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_frames.npz"))
+    cases = {
+        "primary_64x36": dict(W=64, H=36, spp=1, bounces=1, mode=0, flags=abi.FLAG_NOISE_OFF),
+        "primary_160x90": dict(W=160, H=90, spp=1, bounces=1, mode=0, flags=abi.FLAG_NOISE_OFF),
+        "direct_noise_64x36": dict(W=64, H=36, spp=1, bounces=1, mode=0, flags=0),
+        "path_64x36_4spp": dict(W=64, H=36, spp=4, bounces=5, mode=1, flags=0),
+        "path_160x90_4spp": dict(W=160, H=90, spp=4, bounces=5, mode=1, flags=0),
+        "path_fromhit_64x36": dict(W=64, H=36, spp=2, bounces=5, mode=1, flags=abi.FLAG_ORIGIN_FROM_HIT, paths=2),
+    }
+    for name, c in cases.items():
+        W, H = c.pop("W"), c.pop("H")
+        got, acc, _ = hip_render(abi, abi.default_scene(), abi.default_camera(W, H), W, H, seed=SEED, **c)
+        assert_frames_equal(got, g[name + "_target"], name)
+        assert np.array_equal(acc.view(np.uint32), g[name + "_accum"].view(np.uint32)), name
+    got, _, _ = hip_render(abi, abi.synthetic_scene(300), abi.default_camera(48, 27), 48, 27,
+                           spp=2, bounces=5, mode=1, seed=SEED)
+    assert_frames_equal(got, g["synthetic300_48x27_target"], "synthetic300")
+
+
 # ---- flags, scenes, edge cases -------------------------------------------------------
 
 @pytest.mark.parametrize("flags", [2, 4, 8, 2 | 4 | 8, 1 | 2])
