@@ -20,6 +20,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, SPP, BOUNCES, PATHS, SAMPLES, SEED = 1920, 1080, 64, 5, 1, 1, 0x4C554D41
+# --workload: the default is the bench line; the others are the remaining GPU configs of
+# BASELINE.json, for profiling (same JSON shape, `config.workload` says which).
+WORKLOADS = {
+    "config3": dict(w=1920, h=1080, spp=64, bounces=5, mode=1, flags=0, scene=0,
+                    name="default 5-sphere scene 1920x1080, 64 spp/step, 5 bounces, pathtrace paths=1 (BASELINE configs[2])"),
+    "config2": dict(w=1920, h=1080, spp=1, bounces=1, mode=0, flags=1, scene=0,
+                    name="default 5-sphere scene 1920x1080, 1 spp, primary rays only, NOISE_OFF (BASELINE configs[1])"),
+    "config4": dict(w=3840, h=2160, spp=256, bounces=5, mode=1, flags=0, scene=0,
+                    name="default 5-sphere scene 3840x2160, 256 spp/step, 5 bounces, pathtrace (BASELINE configs[3])"),
+    "config5": dict(w=7680, h=4320, spp=16, bounces=5, mode=1, flags=0, scene=4096,
+                    name="synthetic 4096-sphere scene 7680x4320, 16 spp/step, 5 bounces, pathtrace (BASELINE configs[4])"),
+}
 FLOP_PER_TEST, FLOP_PER_RAY = 17.0, 64.0          # SURVEY.md 8d / BASELINE.md section 5
 PEAK_FP32_VALU_TFLOPS = 157.3                     # MI355X_MICROARCH.md, "Peak FP32 (vector)"
 
@@ -54,7 +66,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config3")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="profiling aid: render only band 0 of this many bands on one GPU")
     a = ap.parse_args()
+    global WIDTH, HEIGHT, SPP, BOUNCES
+    wl = WORKLOADS[a.workload]
+    WIDTH, HEIGHT, SPP, BOUNCES = wl["w"], wl["h"], wl["spp"], wl["bounces"]
 
     import torch                                   # before abi.lib(): one shared HIP runtime
     import torch.distributed as dist
@@ -70,13 +88,13 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    y0, y1 = bands.band_rows(HEIGHT, world, rank)
+    y0, y1 = bands.band_rows(HEIGHT, a.emulate_world or world, rank)
     ctx = abi.Context(local)
-    ctx.set_scene(abi.default_scene())
+    ctx.set_scene(abi.synthetic_scene(wl["scene"], SEED) if wl["scene"] else abi.default_scene())
     ctx.set_camera(abi.default_camera(WIDTH, HEIGHT))
     ctx.set_frame(WIDTH, HEIGHT, y0, y1)
     params = abi.make_params(WIDTH, HEIGHT, spp=SPP, bounces=BOUNCES, paths=PATHS, samples=SAMPLES,
-                             mode=abi.MODE_PATHTRACE, flags=0, seed=SEED)
+                             mode=wl["mode"], flags=wl["flags"], seed=SEED)
     band = torch.empty((y1 - y0, WIDTH), dtype=torch.int32, device=dev)
     stream = torch.cuda.Stream(device=dev)          # a real (non-null) stream: kernels, gather and events share it
     torch.cuda.set_stream(stream)
@@ -135,18 +153,18 @@ def main():
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"default 5-sphere scene {WIDTH}x{HEIGHT}, {SPP} spp/step, {BOUNCES} bounces, "
-                                   f"pathtrace paths={PATHS}, seed 0x{SEED:08X} (BASELINE configs[2])",
+            "config": {"workload": wl["name"] + f", seed 0x{SEED:08X}"
+                                   + (f", band 0 of {a.emulate_world} only" if a.emulate_world else ""),
                        "parallelism": f"{world} scanline band(s), RCCL gather to rank 0"},
             "frame_ms": ms_per_step,
-            "msamples_per_s": WIDTH * HEIGHT * SPP * a.steps / dt / 1e6,
+            "msamples_per_s": WIDTH * (HEIGHT // (a.emulate_world or 1)) * SPP * a.steps / dt / 1e6,
             "rays_per_step": rays_per_step,
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
                          "kernel": "luma::render_kernel", "flop_model": "17*sphere_tests + 64*rays (SURVEY 8d)"},
         }
-        if not a.no_cpu_baseline and world == 1:
+        if not a.no_cpu_baseline and world == 1 and a.workload == "config3" and not a.emulate_world:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
 

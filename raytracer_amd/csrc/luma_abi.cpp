@@ -17,6 +17,8 @@ namespace {
 
 thread_local char g_last_error[512] = "";
 
+constexpr size_t kCounterBytes = sizeof(unsigned long long) * luma::kCounterSlots * luma::kCounterStride;
+
 int fail(int code, const char* what, const char* detail)
 {
     std::snprintf(g_last_error, sizeof g_last_error, "%s: %s", what, detail ? detail : "");
@@ -90,9 +92,9 @@ struct luma_ctx {
     uint32_t frame_index = 0;
     bool have_frame = false;
 
-    unsigned long long* d_counters = nullptr;  // [0] rays traced since luma_hip_create (never reset)
+    unsigned long long* d_counters = nullptr;  // rays traced since luma_hip_create, in kCounterSlots partial sums
     unsigned long long* h_counters = nullptr;  // pinned
-    unsigned long long rays_reported = 0;      // part of d_counters[0] already handed out in a luma_stats
+    unsigned long long rays_reported = 0;      // part of that total already handed out in a luma_stats
 
     size_t band_pixels() const { return static_cast<size_t>(row_end - row_begin) * width; }
 };
@@ -183,14 +185,15 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
 
 int collect_stats(luma_ctx* ctx, hipStream_t stream, luma_stats* stats)
 {
-    LUMA_HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, sizeof(unsigned long long),
-                                hipMemcpyDeviceToHost, stream));
+    LUMA_HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, kCounterBytes, hipMemcpyDeviceToHost, stream));
     LUMA_HIP_TRY(hipStreamSynchronize(stream));
+    unsigned long long total = 0;
+    for (uint32_t i = 0; i < luma::kCounterSlots; i++) { total += ctx->h_counters[i * luma::kCounterStride]; }
     float ms = 0.f;
     LUMA_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     stats->kernel_ms = ms;
-    stats->rays = ctx->h_counters[0] - ctx->rays_reported;   // since the previous luma_stats
-    ctx->rays_reported = ctx->h_counters[0];
+    stats->rays = total - ctx->rays_reported;   // since the previous luma_stats
+    ctx->rays_reported = total;
     stats->sphere_tests = stats->rays * ctx->n_spheres;   // every ray scans every sphere (Renderer.cpp:242)
     return LUMA_OK;
 }
@@ -241,9 +244,9 @@ int luma_hip_create(luma_ctx** out, int device_id)
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { return bail(e, "hipStreamCreate"); }
     if ((e = hipEventCreate(&ctx->ev_begin)) != hipSuccess) { return bail(e, "hipEventCreate"); }
     if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) { return bail(e, "hipEventCreate"); }
-    if ((e = hipMalloc(&ctx->d_counters, 2 * sizeof(unsigned long long))) != hipSuccess) { return bail(e, "hipMalloc(counters)"); }
-    if ((e = hipHostMalloc(&ctx->h_counters, 2 * sizeof(unsigned long long))) != hipSuccess) { return bail(e, "hipHostMalloc(counters)"); }
-    if ((e = hipMemset(ctx->d_counters, 0, 2 * sizeof(unsigned long long))) != hipSuccess) { return bail(e, "hipMemset(counters)"); }
+    if ((e = hipMalloc(&ctx->d_counters, kCounterBytes)) != hipSuccess) { return bail(e, "hipMalloc(counters)"); }
+    if ((e = hipHostMalloc(&ctx->h_counters, kCounterBytes)) != hipSuccess) { return bail(e, "hipHostMalloc(counters)"); }
+    if ((e = hipMemset(ctx->d_counters, 0, kCounterBytes)) != hipSuccess) { return bail(e, "hipMemset(counters)"); }
     *out = ctx;
     return LUMA_OK;
 }

@@ -19,6 +19,10 @@ enum : uint32_t { MODE_RAYTRACE = 0, MODE_PATHTRACE = 1 };
 // => up to 5056 spheres are scanned from LDS, larger scenes from global memory.
 static constexpr size_t kMaxSceneLdsBytes = 158 * 1024;
 
+// The ray counter is kCounterSlots 64-bit slots, one per 64-byte line (stride in u64).
+static constexpr uint32_t kCounterSlots = 256;
+static constexpr uint32_t kCounterStride = 8;
+
 // Passed by value as the kernel argument (lands in SGPRs / the kernarg segment).
 struct RenderArgs {
     // frame geometry: this launch renders rows [row_begin,row_end) of width x height
@@ -43,7 +47,7 @@ struct RenderArgs {
     // outputs (band-local)
     float*    acc[3];           // accumulation planes r, g, b
     uint32_t* target;           // 0x00RRGGBB
-    unsigned long long* counters;  // [0] = rays traced
+    unsigned long long* counters;  // kCounterSlots x kCounterStride: rays traced, summed by the host
 };
 
 size_t     scene_lds_bytes(uint32_t n_spheres);

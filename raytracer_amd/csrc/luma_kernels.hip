@@ -187,15 +187,20 @@ LUMA_DEV Hit finish_hit(const float4* __restrict__ rec_gen, int idx, f3 origin, 
     return h;
 }
 
-// Wave-level sum of a per-lane counter, one atomic per wave.
-LUMA_DEV void wave_add_u64(unsigned long long* dst, uint32_t v)
+// Wave-level sum of a per-lane counter, one atomic per wave.  The counter is split over
+// kCounterSlots cache lines picked by workgroup id: tens of thousands of waves adding into ONE
+// address serialise at the memory side (0.3 ms at 1080p), spread over 256 lines they do not.
+LUMA_DEV void wave_add_u64(unsigned long long* slots, uint32_t v)
 {
     unsigned long long s = v;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         s += __shfl_down(s, off, 64);
     }
-    if ((threadIdx.x & 63) == 0 && s != 0) { atomicAdd(dst, s); }
+    if ((threadIdx.x & 63) == 0 && s != 0) {
+        const uint32_t slot = (blockIdx.y * gridDim.x + blockIdx.x) % kCounterSlots;
+        atomicAdd(slots + slot * kCounterStride, s);
+    }
 }
 
 // ---------------------------------------------------------------------------------
@@ -212,12 +217,17 @@ LUMA_DEV void wave_add_u64(unsigned long long* dst, uint32_t v)
 // lives in registers: one read-modify-write of the accumulation planes and one coalesced
 // store of the packed pixel per launch.
 // ---------------------------------------------------------------------------------
+// Workgroups are WAVES waves arranged wg_waves_x(WAVES) wide: 4 waves = 2x2 (32x8 pixels),
+// 16 waves = 4x4 (64x16 pixels).  The large shape is for scenes whose LDS image limits a CU to
+// one or two workgroups: 16 waves keep 4 per SIMD to cover the LDS latency of the scan.
+constexpr int wg_waves_x(int waves) { return waves == 16 ? 4 : 2; }
+
 // Where the scene lives during the launch: scan records (32 B/sphere) and, when they also
 // fit, the material vectors (24 B/sphere) are staged into LDS once per workgroup.
 enum : int { SCENE_GLOBAL = 0, SCENE_LDS_RECORDS = 1, SCENE_LDS_ALL = 2 };
 
-template <int TILE_W, int SCENE, bool NOISE, bool FROM_HIT>
-__global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
+template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT>
+__global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 {
     // [0,n): camera-origin records; [n,2n): general records; then mat0[n] (float4), mat1[n] (float2)
     extern __shared__ float4 lds_rec[];
@@ -242,11 +252,12 @@ __global__ __launch_bounds__(256) void render_kernel(const RenderArgs A)
         __syncthreads();
     }
 
-    // lane -> pixel inside the wave tile; wave -> tile inside the workgroup (2 x 2)
+    // lane -> pixel inside the wave tile; wave -> tile inside the workgroup (WGX x WGY waves)
     constexpr int TILE_H = 64 / TILE_W;
+    constexpr int WGX = wg_waves_x(WAVES), WGY = WAVES / WGX;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * (2 * TILE_W) + (wave & 1u) * TILE_W + (lane % TILE_W);
-    const uint32_t yl = blockIdx.y * (2 * TILE_H) + (wave >> 1) * TILE_H + (lane / TILE_W);
+    const uint32_t x = blockIdx.x * (WGX * TILE_W) + (wave % WGX) * TILE_W + (lane % TILE_W);
+    const uint32_t yl = blockIdx.y * (WGY * TILE_H) + (wave / WGX) * TILE_H + (lane / TILE_W);
     const uint32_t y = A.row_begin + yl;
     const bool live = (x < A.width) && (y < A.row_end);
 
@@ -427,29 +438,34 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 {
     constexpr int tile_h = 64 / kTileW;
     const uint32_t rows = args.row_end - args.row_begin;
-    const dim3 grid((args.width + 2 * kTileW - 1) / (2 * kTileW), (rows + 2 * tile_h - 1) / (2 * tile_h));
     const size_t rec_bytes = scene_lds_bytes(args.n_spheres);
     const size_t all_bytes = rec_bytes + (size_t)args.n_spheres * (sizeof(float4) + sizeof(float2));
     const int scene = all_bytes <= kMaxSceneLdsBytes ? SCENE_LDS_ALL
                     : rec_bytes <= kMaxSceneLdsBytes ? SCENE_LDS_RECORDS : SCENE_GLOBAL;
     const size_t lds = scene == SCENE_LDS_ALL ? all_bytes : scene == SCENE_LDS_RECORDS ? rec_bytes : 0;
     const bool noise = !(args.flags & FLAG_NOISE_OFF), from_hit = (args.flags & FLAG_ORIGIN_FROM_HIT) != 0;
+    // 8 workgroups of 4 waves fill a CU (32 waves) only while each needs <= 20 KiB of the
+    // 160 KiB LDS; beyond that switch to 16-wave workgroups (2 per CU up to 80 KiB, then 1).
+    const bool big_wg = lds > 20 * 1024;
+    const int wgx = wg_waves_x(big_wg ? 16 : 4), wgy = (big_wg ? 16 : 4) / wgx;
+    const dim3 grid((args.width + wgx * kTileW - 1) / (wgx * kTileW), (rows + wgy * tile_h - 1) / (wgy * tile_h));
 
     using kernel_t = void (*)(const RenderArgs);
-#define LUMA_K(S, N, F) render_kernel<kTileW, S, N, F>
-    static const kernel_t table[3][2][2] = {
-        { { LUMA_K(0, false, false), LUMA_K(0, false, true) }, { LUMA_K(0, true, false), LUMA_K(0, true, true) } },
-        { { LUMA_K(1, false, false), LUMA_K(1, false, true) }, { LUMA_K(1, true, false), LUMA_K(1, true, true) } },
-        { { LUMA_K(2, false, false), LUMA_K(2, false, true) }, { LUMA_K(2, true, false), LUMA_K(2, true, true) } },
+#define LUMA_K(W, S, N, F) render_kernel<kTileW, W, S, N, F>
+#define LUMA_KS(W, S) { { LUMA_K(W, S, false, false), LUMA_K(W, S, false, true) }, { LUMA_K(W, S, true, false), LUMA_K(W, S, true, true) } }
+    static const kernel_t table[2][3][2][2] = {
+        { LUMA_KS(4, 0), LUMA_KS(4, 1), LUMA_KS(4, 2) },
+        { LUMA_KS(16, 0), LUMA_KS(16, 1), LUMA_KS(16, 2) },
     };
+#undef LUMA_KS
 #undef LUMA_K
-    const kernel_t k = table[scene][noise][from_hit];
+    const kernel_t k = table[big_wg][scene][noise][from_hit];
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { return e; }
     }
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, stream, args);
+    hipLaunchKernelGGL(k, grid, dim3(big_wg ? 1024 : 256), lds, stream, args);
     return hipGetLastError();
 }
 
