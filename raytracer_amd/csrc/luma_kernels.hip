@@ -134,7 +134,7 @@ LUMA_DEV f3 camera_ray(const RenderArgs& A, uint32_t x, uint32_t y)
 //   otherwise: `rec` = (centre.xyz, radius) and diff, c are formed per test (:244-248).
 // Returns the winning index (or -1) and t; hit point / normal are formed by the caller for
 // the winner only (the reference normalises every candidate, :264; same values).
-template <bool CAM_ORIGIN>
+template <bool CAM_ORIGIN, bool UNROLL4>
 LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin, f3 dir, float& t_out)
 {
     const float a = dot3(dir, dir);                              // :246 (hoisted: loop invariant)
@@ -146,20 +146,24 @@ LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin,
     const bool odd_a = !(a > 1e-30f && a < 1e30f);
     float best_num = __builtin_inff();
     int best = -1;
-    for (uint32_t i = 0; i < n; i++) {
-        const float4 s = rec[i];
-        float b, c;
+
+    // b (half of :247) and d (quarter of :251) of one sphere
+    auto test = [&](const float4 s, float& b, float& d) {
+        float c;
         if (CAM_ORIGIN) {
-            b = dot3(mk3(s.x, s.y, s.z), dir);                   // :247 (half of it)
+            b = dot3(mk3(s.x, s.y, s.z), dir);
             c = s.w;
         } else {
-            f3 diff = sub3(origin, mk3(s.x, s.y, s.z));          // :244
+            const f3 diff = sub3(origin, mk3(s.x, s.y, s.z));    // :244
             b = dot3(diff, dir);
             c = fma_(-s.w, s.w, dot3(diff, diff));               // :248
         }
-        const float d = fma_(b, b, -(a * c));                    // :251 (quarter of it)
-        // b >= 0 gives -b - sqrt(d) < 0, i.e. t <= 0 (:258 rejects it): skip the sqrt.
-        if (d > 0.0f && b < 0.0f) {                              // :253
+        d = fma_(b, b, -(a * c));
+    };
+    // b >= 0 gives -b - sqrt(d) < 0, i.e. t <= 0 (:258 rejects it): such spheres skip the sqrt.
+    auto candidate = [](float b, float d) { return d > 0.0f && b < 0.0f; };   // :253
+    auto consider = [&](float b, float d, uint32_t i) {
+        if (candidate(b, d)) {
             const float num = -b - sqrt_rn(d);                   // :255, numerator
             if (num > 0.0f && num < best_num) {
                 bool take = true;
@@ -171,6 +175,32 @@ LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin,
                 if (take) { best_num = num; best = (int)i; }
             }
         }
+    };
+
+    // Four records per trip: the four broadcast ds_read_b128 are in flight together (one LDS
+    // round trip per four spheres instead of one each), and one wave-level branch skips the
+    // candidate handling when none of the four is hit by any lane, the common case in a
+    // large scene.  Candidates are still considered in index order (:242, :266).
+    // (Used for scenes big enough to run 16-wave workgroups; small scenes keep the plain
+    // loop, whose 63 VGPRs allow 8 waves per SIMD.)
+    uint32_t i = 0;
+    if (UNROLL4) {
+        for (; i + 4 <= n; i += 4) {
+            const float4 s0 = rec[i], s1 = rec[i + 1], s2 = rec[i + 2], s3 = rec[i + 3];
+            float b0, d0, b1, d1, b2, d2, b3, d3;
+            test(s0, b0, d0); test(s1, b1, d1); test(s2, b2, d2); test(s3, b3, d3);
+            // candidate(b,d) == (min(d,-b) > 0); the max over the four is a cheap superset test
+            const float any = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, -b0), __builtin_fminf(d1, -b1)),
+                                              __builtin_fmaxf(__builtin_fminf(d2, -b2), __builtin_fminf(d3, -b3)));
+            if (any > 0.0f) {
+                consider(b0, d0, i); consider(b1, d1, i + 1); consider(b2, d2, i + 2); consider(b3, d3, i + 3);
+            }
+        }
+    }
+    for (; i < n; i++) {
+        float b, d;
+        test(rec[i], b, d);
+        consider(b, d, i);
     }
     t_out = (best >= 0) ? best_num / a : FLT_MAX;
     return best;
@@ -273,7 +303,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 
         // DOF pre-pass, :416-432.  Noise free, so it is the same for every frame of the call.
         float t0;
-        const int h0 = scan_spheres<true>(rec_cam, n, campos, dir0, t0);
+        const int h0 = scan_spheres<true, (WAVES == 16)>(rec_cam, n, campos, dir0, t0);
         nrays++;
         const float depth = (h0 >= 0) ? t0 : FLT_MAX;            // :419-423
         const float dd = depth - A.focus_depth;                  // :425
@@ -302,8 +332,8 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 
             float t;
             int idx;
-            if (FROM_HIT && bounce > 0) { idx = scan_spheres<false>(rec_gen, n, origin, dn, t); }
-            else                        { idx = scan_spheres<true>(rec_cam, n, origin, dn, t); }   // :304
+            if (FROM_HIT && bounce > 0) { idx = scan_spheres<false, (WAVES == 16)>(rec_gen, n, origin, dn, t); }
+            else                        { idx = scan_spheres<true, (WAVES == 16)>(rec_cam, n, origin, dn, t); }   // :304
             nrays++;
 
             bool path_ends;
@@ -328,7 +358,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
                                 if (dot3(d, hit.normal) < 0.0f) { d = neg3(d); }   // :197-200
                                 const f3 nd = add3(hit.normal, d);     // :202
                                 float tc;
-                                const int ci = scan_spheres<false>(rec_gen, n, hit.pos, nd, tc);   // :204
+                                const int ci = scan_spheres<false, (WAVES == 16)>(rec_gen, n, hit.pos, nd, tc);   // :204
                                 nrays++;
                                 if (ci >= 0) {                   // :206-209
                                     const float4 cm = mat0[ci];
