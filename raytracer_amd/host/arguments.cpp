@@ -1,0 +1,104 @@
+#include "arguments.h"
+
+#include <charconv>
+#include <functional>
+#include <unordered_map>
+
+#include "log.h"
+
+namespace luma {
+
+Options _options;
+
+namespace {
+
+// Whole-string integer, as parse_integer in the reference (arguments.cpp:52-62).
+template <typename T>
+bool whole_number(const std::string& text, T& out, int base = 10)
+{
+    const char* first = text.data();
+    const char* last = first + text.size();
+    if (base == 16 && text.size() > 2 && text[0] == '0' && (text[1] == 'x' || text[1] == 'X')) { first += 2; }
+    const auto [ptr, ec] = std::from_chars(first, last, out, base);
+    return ec == std::errc() && ptr == last && first != last;
+}
+
+using Setter = std::function<bool(const std::string&)>;   // false: value not understood
+
+template <typename T>
+Setter number_into(T& field)
+{
+    return [&field](const std::string& v) { T parsed{}; if (!whole_number(v, parsed)) { return false; } field = parsed; return true; };
+}
+
+}  // namespace
+
+void Arguments::parse(const std::vector<std::string>& arguments)
+{
+    struct Entry { const char* what; Setter set; };
+    const std::unordered_map<std::string, Entry> table{
+        { "width",   { "image width", number_into(_options.width) } },
+        { "height",  { "image height", number_into(_options.height) } },
+        { "samples", { "image samples", number_into(_options.samples) } },
+        { "bounces", { "image bounces", number_into(_options.bounces) } },
+        { "paths",   { "path count", [](const std::string& v) {
+            if (_options.mode != RenderMode::PATHTRACE) {   // arguments.cpp:179-183: warn, keep going
+                warning("path count `" + v + "` will be ignored if render mode is not set to \"pathtrace\"");
+            }
+            return number_into(_options.paths)(v); } } },
+        { "mode",    { "mode", [](const std::string& v) {
+            if (v == "raytrace") { _options.mode = RenderMode::RAYTRACE; return true; }
+            if (v == "pathtrace") { _options.mode = RenderMode::PATHTRACE; return true; }
+            return false; } } },
+        { "context", { "context", [](const std::string& v) {
+            if (v == "interative" || v == "interactive") { _options.context = Context::INTERACTIVE; return true; }   // arguments.h:30 spells it "interative"
+            if (v == "directx") { _options.context = Context::DIRECTX; return true; }
+            if (v == "headless") { _options.context = Context::HEADLESS; return true; }
+            return false; } } },
+        { "backend", { "backend", [](const std::string& v) {
+            if (v == "cpu") { _options.backend = Backend::CPU; return true; }
+            if (v == "hip") { _options.backend = Backend::HIP; return true; }
+            return false; } } },
+        { "gpus",    { "gpu count", [](const std::string& v) {
+            std::uint32_t n = 0;
+            if (!whole_number(v, n) || n < 1 || n > 8) { return false; }
+            _options.gpus = n; return true; } } },
+        { "seed",    { "seed", [](const std::string& v) {
+            std::uint64_t s = 0;
+            const bool hex = v.size() > 2 && v[0] == '0' && (v[1] == 'x' || v[1] == 'X');
+            if (!whole_number(v, s, hex ? 16 : 10)) { return false; }
+            _options.seed = s; return true; } } },
+        { "frames",  { "frame count", number_into(_options.frames) } },
+        { "flags",   { "flags", number_into(_options.flags) } },
+        { "output",  { "output path", [](const std::string& v) { if (v.empty()) { return false; } _options.output = v; return true; } } },
+    };
+
+    for (std::size_t i = 0; i < arguments.size(); i++) {
+        const std::string& argument = arguments[i];
+        if (argument.rfind("--", 0) != 0) {
+            log("invalid argument `" + argument + "`");              // arguments.cpp:227-230
+            continue;
+        }
+        std::string key = argument.substr(2), value;
+        const auto eq = key.find('=');
+        if (eq != std::string::npos) {                               // --key=value (arguments.cpp:103)
+            value = key.substr(eq + 1);
+            key.erase(eq);
+        } else if (i + 1 < arguments.size() && arguments[i + 1].rfind("--", 0) != 0) {
+            value = arguments[++i];                                  // --key value (BASELINE.json's spelling)
+        } else {
+            log("unrecognized option format `" + argument + "`");    // arguments.cpp:107
+            continue;
+        }
+        const auto it = table.find(key);
+        if (it == table.end()) {
+            log("unrecognized option `" + key + "`");                // arguments.cpp:115
+            continue;
+        }
+        if (!it->second.set(value)) {
+            log(std::string("unrecognized ") + it->second.what + " `" + value + "`");   // arguments.cpp:131 etc.
+        }
+    }
+}
+
+}  // namespace luma

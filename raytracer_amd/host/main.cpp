@@ -1,0 +1,67 @@
+// main.cpp -- headless Linux entry point, shaped like the reference's HEADLESS context
+// (main.cpp:241-287): construct the Renderer, call render_to once per frame, report
+// "[DELIVERED FRAME]:n:ms" per frame, then write the frame with Image::export_to_ppm
+// (the reference's Ctrl+P path, main.cpp:95-102).  Display (olc, D3D11) is not built.
+//
+//   luma_headless --backend hip --width=1920 --height=1080 --mode=pathtrace --bounces=5
+//                 --samples=1 --paths=1 --frames=64 --output=frame.ppm
+#include <chrono>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "arguments.h"
+#include "image.h"
+#include "log.h"
+#include "renderer.h"
+
+int main(int argc, char** argv)
+{
+    std::vector<std::string> args(argv + (argc > 0 ? 1 : 0), argv + argc);
+    luma::_options.context = luma::Context::HEADLESS;
+    luma::_options.backend = luma::Backend::HIP;
+    luma::Arguments{}.parse(args);
+
+    if (luma::_options.context != luma::Context::HEADLESS) {
+        luma::log("only --context=headless is built on Linux (the interactive and directx contexts need a window)");
+        return 2;
+    }
+    if (luma::_options.gpus != 1) {
+        luma::log("--gpus=N runs one process per GPU: launch bench.py with torch.distributed.run (INTEGRATION.md section 3)");
+        return 2;
+    }
+    if (luma::_options.width == 0 || luma::_options.height == 0) {
+        luma::log("--width and --height must be positive");
+        return 2;
+    }
+
+    luma::Renderer renderer{};
+    const std::size_t pixels = static_cast<std::size_t>(luma::_options.width) * luma::_options.height;
+    std::unique_ptr<std::uint32_t[]> framebuffer(new std::uint32_t[pixels]());
+
+    auto then = std::chrono::high_resolution_clock::now();
+    double kernel_ms = 0.0;
+    unsigned long long rays = 0;
+    for (std::uint32_t frame = 0; frame < luma::_options.frames; frame++) {
+        renderer.render_to(framebuffer.get(), nullptr);
+        const auto now = std::chrono::high_resolution_clock::now();
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(now - then).count();
+        then = now;
+        kernel_ms += renderer.last_stats().kernel_ms;
+        rays += renderer.last_stats().rays;
+        std::printf("[DELIVERED FRAME]:%u:%lld\n", frame, static_cast<long long>(ms));
+    }
+    if (kernel_ms > 0.0) {
+        std::printf("[STATS]:frames=%u:rays=%llu:kernel_ms=%.3f:Mrays/s=%.1f\n", luma::_options.frames, rays, kernel_ms,
+                    static_cast<double>(rays) / kernel_ms / 1e3);
+    }
+
+    luma::Image image{ static_cast<std::int32_t>(luma::_options.width), static_cast<std::int32_t>(luma::_options.height), false };
+    image.shadow_from(framebuffer.get());
+    const std::string& out = luma::_options.output;
+    if (out.size() > 4 && out.compare(out.size() - 4, 4, ".bmp") == 0) { image.export_to_bmp(out); }
+    else { image.export_to_ppm(out); }
+    luma::log("wrote `" + out + "`");
+    return 0;
+}

@@ -1,0 +1,78 @@
+#include "renderer.h"
+
+#include <chrono>
+#include <cstdlib>
+
+#include "arguments.h"
+#include "log.h"
+
+namespace luma {
+
+namespace {
+
+[[noreturn]] void die(const char* where)
+{
+    log(std::string(where) + ": " + luma_hip_last_error());
+    std::abort();   // render_to is noexcept with no status channel (renderer.h:76): fail loudly
+}
+
+}  // namespace
+
+Renderer::Renderer() noexcept
+    : camera(70.0f, 0.1f, 100.0f, _options.width, _options.height)   // Renderer.cpp:164
+{
+    spheres.resize(5);
+    luma_scene_default(reinterpret_cast<luma_sphere*>(spheres.data()));   // renderer.h:62-70
+
+    if (_options.backend != Backend::HIP) {
+        log("this build has only the HIP backend (--backend=hip); the CPU loop is the reference's own Renderer.cpp");
+        std::abort();
+    }
+    if (luma_hip_create(&ctx_, -1) != LUMA_OK) { die("luma_hip_create"); }
+    if (luma_hip_set_frame(ctx_, _options.width, _options.height, 0, _options.height) != LUMA_OK) { die("luma_hip_set_frame"); }
+}
+
+Renderer::~Renderer() { luma_hip_destroy(ctx_); }
+
+void Renderer::render_to(std::uint32_t* target, olc::PixelGameEngine* pge) noexcept
+{
+    // pge->Clear / DrawCircle (Renderer.cpp:368, :445) are display only and stay out of this path.
+    const auto begin = std::chrono::steady_clock::now();             // fx::Timer, :370
+
+    camera.update(frametime, pge);                                   // :375
+    if (scene_dirty_) {
+        if (luma_hip_set_scene(ctx_, reinterpret_cast<const luma_sphere*>(spheres.data()),
+                               static_cast<std::uint32_t>(spheres.size())) != LUMA_OK) { die("luma_hip_set_scene"); }
+        scene_dirty_ = false;
+    }
+    const luma_camera cam = camera.abi();
+    if (luma_hip_set_camera(ctx_, &cam) != LUMA_OK) { die("luma_hip_set_camera"); }
+    if (camera.moved) {                                              // :377-390
+        frame_count = 1.f;
+        if (luma_hip_reset(ctx_) != LUMA_OK) { die("luma_hip_reset"); }
+        camera.moved = false;
+    }
+
+    luma_params p{};
+    p.width = _options.width;
+    p.height = _options.height;
+    p.samples = _options.samples;
+    p.bounces = _options.bounces;
+    p.paths = _options.paths;
+    p.mode = _options.mode == RenderMode::PATHTRACE ? LUMA_MODE_PATHTRACE : LUMA_MODE_RAYTRACE;
+    p.spp = 1;                                                       // one render_to == one frame
+    p.flags = _options.flags;
+    p.seed = _options.seed;
+    if (luma_hip_render(ctx_, &p, target, &stats_) != LUMA_OK) { die("luma_hip_render"); }   // :392-467
+
+    frametime = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - begin).count();   // :469
+    frame_count += 1.f;                                              // :470
+}
+
+bool Renderer::sync_accumulated_data()
+{
+    accumulated_data.resize(static_cast<std::size_t>(_options.width) * _options.height);
+    return luma_hip_read_accum(ctx_, accumulated_data.data()->data()) == LUMA_OK;
+}
+
+}  // namespace luma

@@ -1,0 +1,73 @@
+"""The headless C++ host (raytracer_amd/host/): luma::Arguments / Renderer / Camera / Image over
+the C-ABI.  CPU tests cover the flag parser's log-and-continue behaviour (arguments.cpp:105-117,
+:227-230); the GPU test renders through `luma_headless --backend hip` and compares the PPM it
+writes, byte for byte, with the oracle's frame written by the oracle's PPM writer."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "raytracer_amd", "luma_headless")
+
+
+def run(*args, timeout=120):
+    return subprocess.run([EXE, *args], capture_output=True, text=True, timeout=timeout)
+
+
+def test_parser_logs_and_continues():
+    # --context=directx makes main() return 2 right after parsing, before any GPU call
+    r = run("--context=directx", "--width=abc", "--bogus=1", "stray", "--mode=fancy", "--paths=3", "--height")
+    assert r.returncode == 2
+    out = r.stdout
+    assert "[INFORMATION]: unrecognized image width `abc`" in out
+    assert "[INFORMATION]: unrecognized option `bogus`" in out
+    assert "[INFORMATION]: invalid argument `stray`" in out
+    assert "[INFORMATION]: unrecognized mode `fancy`" in out
+    assert "[WARNING]: path count `3` will be ignored if render mode is not set to \"pathtrace\"" in out
+    assert "[INFORMATION]: unrecognized option format `--height`" in out
+    assert "only --context=headless" in out
+
+
+def test_parser_space_and_equals_forms():
+    r = run("--backend", "hip", "--gpus", "4", "--width=64", "--height", "36")
+    assert r.returncode == 2 and "one process per GPU" in r.stdout      # --gpus 4 parsed from the space form
+    r = run("--gpus=9", "--context=directx")
+    assert "unrecognized gpu count `9`" in r.stdout
+    r = run("--width=0", "--height=10")
+    assert r.returncode == 2 and "must be positive" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args,okw", [
+    (["--width=96", "--height=54", "--mode=raytrace", "--bounces=1", "--samples=1", "--frames=1", "--flags=1"],
+     dict(spp=1, bounces=1, mode=0, flags=1)),
+    (["--width=96", "--height=54", "--mode=pathtrace", "--bounces", "5", "--samples=1", "--paths=1", "--frames=6",
+      "--seed=0x4C554D41"], dict(spp=6, bounces=5, mode=1, flags=0)),
+])
+def test_headless_ppm_matches_oracle(tmp_path, oracle, args, okw):
+    out = tmp_path / "frame.ppm"
+    r = run("--backend", "hip", *args, f"--output={out}")
+    assert r.returncode == 0, r.stdout + r.stderr
+    frames = [ln for ln in r.stdout.splitlines() if ln.startswith("[DELIVERED FRAME]:")]
+    assert len(frames) == okw["spp"] and frames[0].startswith("[DELIVERED FRAME]:0:")
+    W, H = 96, 54
+    want, _, _ = oracle.render(oracle.default_scene(), oracle.camera(W, H),
+                               oracle.make_params(W, H, seed=0x4C554D41, **okw))
+    ref = tmp_path / "oracle.ppm"
+    assert oracle.export_ppm(want, str(ref)) == 0
+    assert out.read_bytes() == ref.read_bytes()
+
+
+@pytest.mark.gpu
+def test_headless_bmp(tmp_path, oracle):
+    out = tmp_path / "frame.bmp"
+    r = run("--backend=hip", "--width=33", "--height=17", "--mode=raytrace", "--bounces=1", "--frames=1", "--flags=1",
+            f"--output={out}")
+    assert r.returncode == 0, r.stdout + r.stderr
+    want, _, _ = oracle.render(oracle.default_scene(), oracle.camera(33, 17),
+                               oracle.make_params(33, 17, spp=1, bounces=1, mode=0, flags=1))
+    ref = tmp_path / "oracle.bmp"
+    assert oracle.export_bmp(want, str(ref)) == 0
+    assert out.read_bytes() == ref.read_bytes()
