@@ -19,6 +19,10 @@ enum : uint32_t { MODE_RAYTRACE = 0, MODE_PATHTRACE = 1 };
 // => up to 5056 spheres are scanned from LDS, larger scenes from global memory.
 static constexpr size_t kMaxSceneLdsBytes = 158 * 1024;
 
+// Scenes with at least this many spheres (and whose padded records fit in LDS) use the
+// sphere-parallel scan (render_kernel_sp); smaller ones the ray-per-lane scan.
+static constexpr uint32_t kSphereParallelMin = 192;
+
 // The ray counter is kCounterSlots 64-bit slots, one per 64-byte line (stride in u64).
 static constexpr uint32_t kCounterSlots = 256;
 static constexpr uint32_t kCounterStride = 8;

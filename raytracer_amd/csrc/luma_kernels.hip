@@ -254,7 +254,7 @@ constexpr int wg_waves_x(int waves) { return waves == 16 ? 4 : 2; }
 
 // Where the scene lives during the launch: scan records (32 B/sphere) and, when they also
 // fit, the material vectors (24 B/sphere) are staged into LDS once per workgroup.
-enum : int { SCENE_GLOBAL = 0, SCENE_LDS_RECORDS = 1, SCENE_LDS_ALL = 2 };
+enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 
 template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT>
 __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 
         // DOF pre-pass, :416-432.  Noise free, so it is the same for every frame of the call.
         float t0;
-        const int h0 = scan_spheres<true, (WAVES == 16)>(rec_cam, n, campos, dir0, t0);
+        const int h0 = scan_spheres<true, (SCENE == SCENE_GLOBAL)>(rec_cam, n, campos, dir0, t0);
         nrays++;
         const float depth = (h0 >= 0) ? t0 : FLT_MAX;            // :419-423
         const float dd = depth - A.focus_depth;                  // :425
@@ -332,8 +332,8 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 
             float t;
             int idx;
-            if (FROM_HIT && bounce > 0) { idx = scan_spheres<false, (WAVES == 16)>(rec_gen, n, origin, dn, t); }
-            else                        { idx = scan_spheres<true, (WAVES == 16)>(rec_cam, n, origin, dn, t); }   // :304
+            if (FROM_HIT && bounce > 0) { idx = scan_spheres<false, (SCENE == SCENE_GLOBAL)>(rec_gen, n, origin, dn, t); }
+            else                        { idx = scan_spheres<true, (SCENE == SCENE_GLOBAL)>(rec_cam, n, origin, dn, t); }   // :304
             nrays++;
 
             bool path_ends;
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
                                 if (dot3(d, hit.normal) < 0.0f) { d = neg3(d); }   // :197-200
                                 const f3 nd = add3(hit.normal, d);     // :202
                                 float tc;
-                                const int ci = scan_spheres<false, (WAVES == 16)>(rec_gen, n, hit.pos, nd, tc);   // :204
+                                const int ci = scan_spheres<false, (SCENE == SCENE_GLOBAL)>(rec_gen, n, hit.pos, nd, tc);   // :204
                                 nrays++;
                                 if (ci >= 0) {                   // :206-209
                                     const float4 cm = mat0[ci];
@@ -419,6 +419,284 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
     wave_add_u64(A.counters, nrays);
 }
 
+// ---------------------------------------------------------------------------------
+// Sphere-parallel variant for large scenes (n >= kSphereParallelMin).
+//
+// With thousands of spheres the scan is >99 % of the work and "one lane = one ray" wastes it
+// twice: lanes whose path has ended (or that have no indirect ray this step) idle through a
+// whole N-sphere scan, and every lane re-reads the same record.  Here the scan is turned
+// around: the wave takes ONE ray at a time, broadcasts it to SGPRs (v_readlane), and its 64
+// lanes test 64 DIFFERENT spheres per instruction, reading 1 KiB of records per ds_read_b128
+// (conflict free: 16 B per lane, contiguous).  Every lane does useful work on every scan
+// instruction whatever the divergence of the paths; rays that do not exist are simply not
+// scanned.  Each lane keeps the best (t, index) among its own spheres (its indices ascend, so
+// the strict `<` of Renderer.cpp:266 holds), and a 6-step butterfly over the packed key
+// (t bits << 32 | index) picks the lexicographic minimum: the smallest t, and among equal t
+// the lowest index, which is exactly what the reference's in-order scan returns.  The rest of
+// the loop (RNG, shading, accumulation) stays one lane = one pixel.
+// ---------------------------------------------------------------------------------
+
+// Scan for lane `j`'s ray over records laid out [batch][lane] in LDS; n_pad is a multiple of
+// 256 and the padding records are NaN (never a candidate).  All 64 lanes must call this.
+template <bool CAM_ORIGIN>
+LUMA_DEV unsigned long long wave_scan_one(const float4* __restrict__ rec, uint32_t n_pad, uint32_t lane,
+                                          float ox, float oy, float oz, float dx, float dy, float dz, float a)
+{
+    float best_t = FLT_MAX;                                      // :236-238
+    uint32_t best_i = 0xFFFFFFFFu;
+
+    auto test = [&](const float4 s, float& b, float& d) {
+        float c;
+        if (CAM_ORIGIN) {
+            b = fma_(s.z, dz, fma_(s.y, dy, s.x * dx));          // :247 (half), diff precomputed
+            c = s.w;
+        } else {
+            const float fx = ox - s.x, fy = oy - s.y, fz = oz - s.z;   // :244
+            b = fma_(fz, dz, fma_(fy, dy, fx * dx));
+            c = fma_(-s.w, s.w, fma_(fz, fz, fma_(fy, fy, fx * fx)));  // :248
+        }
+        d = fma_(b, b, -(a * c));                                // :251 (quarter)
+    };
+    auto consider = [&](float b, float d, uint32_t i) {
+        if (d > 0.0f && b < 0.0f) {                              // :253 (b >= 0 gives t <= 0, rejected at :258)
+            const float t = (-b - sqrt_rn(d)) / a;               // :255
+            if (t > 0.0f && t < best_t) { best_t = t; best_i = i; }   // :258, :266
+        }
+    };
+
+    for (uint32_t base = 0; base < n_pad; base += 256) {
+        const float4 s0 = rec[base + lane], s1 = rec[base + 64 + lane];
+        const float4 s2 = rec[base + 128 + lane], s3 = rec[base + 192 + lane];
+        float b0, d0, b1, d1, b2, d2, b3, d3;
+        test(s0, b0, d0); test(s1, b1, d1); test(s2, b2, d2); test(s3, b3, d3);
+        const float any = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, -b0), __builtin_fminf(d1, -b1)),
+                                          __builtin_fmaxf(__builtin_fminf(d2, -b2), __builtin_fminf(d3, -b3)));
+        if (any > 0.0f) {
+            consider(b0, d0, base + lane); consider(b1, d1, base + 64 + lane);
+            consider(b2, d2, base + 128 + lane); consider(b3, d3, base + 192 + lane);
+        }
+    }
+
+    // lexicographic min of (t, index) over the wave; t > 0 so its bit pattern orders like the value
+    unsigned long long key = (best_i == 0xFFFFFFFFu)
+        ? ~0ull : (((unsigned long long)__builtin_bit_cast(uint32_t, best_t) << 32) | best_i);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long other = __shfl_xor(key, off, 64);
+        key = other < key ? other : key;
+    }
+    return key;
+}
+
+// Scans the ray of every lane with want == true (one after the other) and returns, in that
+// lane, the closest hit (index or -1, and t).  Wave-uniform control flow: every lane calls it.
+template <bool CAM_ORIGIN>
+LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t lane, bool want,
+                        f3 origin, f3 dir, int& idx, float& t)
+{
+    const float a = dot3(dir, dir);                              // :246, per lane, then broadcast
+    idx = -1;
+    t = FLT_MAX;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(want);
+    while (todo) {
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dir.x), j));
+        const float dy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dir.y), j));
+        const float dz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dir.z), j));
+        const float aj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), j));
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        if (!CAM_ORIGIN) {
+            ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, origin.x), j));
+            oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, origin.y), j));
+            oz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, origin.z), j));
+        }
+        const unsigned long long key = wave_scan_one<CAM_ORIGIN>(rec, n_pad, lane, ox, oy, oz, dx, dy, dz, aj);
+        if (lane == (uint32_t)j && key != ~0ull) {
+            idx = (int)(uint32_t)key;
+            t = __builtin_bit_cast(float, (uint32_t)(key >> 32));
+        }
+    }
+}
+
+template <int TILE_W, int WAVES, bool NOISE, bool FROM_HIT>
+__global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs A)
+{
+    // [0,n_pad): camera-origin records; [n_pad,2 n_pad): general records; padding = NaN
+    extern __shared__ float4 lds_rec[];
+    const uint32_t n = A.n_spheres;
+    const uint32_t n_pad = (n + 255u) & ~255u;
+    {
+        const float qnan = __builtin_nanf("");
+        const float4 never = make_float4(qnan, qnan, qnan, qnan);
+        for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
+            lds_rec[i] = (i < n) ? A.records[i] : never;
+            lds_rec[n_pad + i] = (i < n) ? A.records[n + i] : never;
+        }
+        __syncthreads();
+    }
+    const float4* rec_cam = lds_rec;
+    const float4* rec_gen = lds_rec + n_pad;
+
+    constexpr int TILE_H = 64 / TILE_W;
+    constexpr int WGX = wg_waves_x(WAVES), WGY = WAVES / WGX;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * (WGX * TILE_W) + (wave % WGX) * TILE_W + (lane % TILE_W);
+    const uint32_t yl = blockIdx.y * (WGY * TILE_H) + (wave / WGX) * TILE_H + (lane / TILE_W);
+    const uint32_t y = A.row_begin + yl;
+    const bool live = (x < A.width) && (y < A.row_end);
+
+    const uint32_t pixel = y * A.width + x;                      // global index (:399); unused when !live
+    const uint32_t local = yl * A.width + x;
+    const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
+    const uint32_t slots = 2u + A.paths;
+    const bool pathtrace = A.mode == MODE_PATHTRACE;
+    uint32_t nrays = 0;
+
+    const f3 dir0 = camera_ray(A, live ? x : 0u, live ? y : 0u); // camera.rays[index], :413
+
+    // DOF pre-pass, :416-432
+    int h0;
+    float t0;
+    wave_scan<true>(rec_cam, n_pad, lane, live, campos, dir0, h0, t0);
+    nrays += live ? 1u : 0u;
+    const float depth = (h0 >= 0) ? t0 : FLT_MAX;                // :419-423
+    const float dd = depth - A.focus_depth;                      // :425
+    const float x2 = dd * dd, x4 = x2 * x2, x8 = x4 * x4, x10 = x8 * x2;
+    const float focus = 1.0f - luma_expf(-x10);                  // :427
+    const float blur = fma_(focus, 4.5f, 0.5f);                  // :429-432
+    const float gainf = (A.show_depth && (focus < .5f)) ? 1.2f : 1.0f;   // :448-452
+
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
+    if (live) { acc_r = A.acc[0][local]; acc_g = A.acc[1][local]; acc_b = A.acc[2][local]; }
+
+    uint32_t s = 0, bounce = 0;
+    f3 direct = mk3(0.f, 0.f, 0.f);
+    f3 dir = dir0;                                               // :293
+    f3 origin = campos;                                          // :294, :303
+    const uint32_t spp = (A.bounces && live) ? A.spp : 0u;       // bounces == 0: every sample adds +0
+
+    // One (sample, bounce) step per trip for every lane that still has samples; the loop itself
+    // is wave uniform because the scans are cooperative.
+    while (__builtin_amdgcn_ballot_w64(s < spp)) {
+        const bool active = s < spp;
+        const uint32_t sample = A.frame_index + s;
+        const uint32_t slot = bounce * slots;
+
+        f3 dn = dir;
+        if (active) {
+            if (NOISE) { dn = add3(dir, rng_vec3(A, pixel, sample, slot, -blur, blur)); }   // :118-119, :302
+            else       { dn = add3(dir, mk3(0.f, 0.f, 0.f)); }
+        }
+
+        int idx;
+        float t;
+        if (FROM_HIT) {
+            int i2; float t2;
+            wave_scan<true>(rec_cam, n_pad, lane, active && bounce == 0, origin, dn, idx, t);
+            wave_scan<false>(rec_gen, n_pad, lane, active && bounce > 0, origin, dn, i2, t2);
+            if (bounce > 0) { idx = i2; t = t2; }
+        } else {
+            wave_scan<true>(rec_cam, n_pad, lane, active, origin, dn, idx, t);   // :304
+        }
+        nrays += active ? 1u : 0u;
+
+        // shading up to the point where indirect rays are needed
+        bool path_ends = false, want_indirect = false, lit = false;
+        Hit hit; hit.pos = campos; hit.normal = mk3(0.f, 0.f, 1.f);
+        float4 m0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        float2 m1 = make_float2(0.f, 0.f);
+        float cos_theta = 0.f;
+        if (active) {
+            if (idx < 0) {                                       // :306-319
+                const float clamped = __builtin_fminf(__builtin_fmaxf(dn.y, -1.f), 1.f);
+                const float adjusted = (clamped + 1.f) * .5f;
+                direct = add3(direct, color_lerp(mk3(.529f, .808f, .922f), mk3(.106f, .275f, .711f), adjusted));
+                path_ends = true;
+            } else {
+                hit = finish_hit(rec_gen, idx, origin, dn, t);
+                m0 = A.mat0[idx];                                // diffuse rgb, albedo
+                m1 = A.mat1[idx];                                // metallic, roughness
+                cos_theta = dot3(neg3(dn), hit.normal);          // :331-332
+                lit = cos_theta >= 0.0f;                         // :334
+                want_indirect = lit && (m0.w > 0.0f) && pathtrace;   // :337, :187
+            }
+        }
+
+        // indirect_illumination, :182-216: `paths` cooperative scans from the hit points
+        f3 indirect = mk3(0.f, 0.f, 0.f);
+        for (uint32_t p = 0; p < A.paths; p++) {                 // :192
+            f3 nd = mk3(0.f, 0.f, 1.f);
+            if (want_indirect) {
+                f3 d = normalize3(rng_vec3(A, pixel, sample, slot + 2u + p, -1.0f, 1.0f));   // :194
+                if (dot3(d, hit.normal) < 0.0f) { d = neg3(d); } // :197-200
+                nd = add3(hit.normal, d);                        // :202
+            }
+            int ci; float tc;
+            wave_scan<false>(rec_gen, n_pad, lane, want_indirect, hit.pos, nd, ci, tc);   // :204
+            if (want_indirect) {
+                nrays++;
+                if (ci >= 0) {                                   // :206-209
+                    const float4 cm = A.mat0[ci];
+                    indirect = add3(indirect, mk3(cm.x, cm.y, cm.z));
+                }
+            }
+        }
+
+        if (active && idx >= 0) {
+            if (lit) {
+                if (m0.w > 0.0f) {
+                    indirect = scale3(indirect, A.inv_samples);  // :212-213
+                    indirect = scale3(indirect, m0.w);           // :340
+                }
+                const float value = (cos_theta + 1.f) * .5f;     // :343
+                const float scalar = value * (1.f - m1.x);       // :345
+                const f3 capture = color_lerp(mk3(m0.x, m0.y, m0.z), indirect, 1.f - scalar);   // :346
+                direct = fma3(capture, scalar * .8f, direct);    // :347-349
+            }
+            bounce++;
+            path_ends = (m1.x == 0.0f) || (bounce == A.bounces); // :353-357, :300
+            if (!path_ends) {
+                f3 nrm = hit.normal;
+                if (NOISE) {
+                    const float gain = .2f * m1.y;               // :225
+                    nrm = add3(nrm, rng_vec3(A, pixel, sample, slot + 1u, -gain, gain));   // :226-227
+                } else {
+                    nrm = add3(nrm, mk3(0.f, 0.f, 0.f));
+                }
+                const float k = 2.0f * dot3(dn, nrm);            // fx::reflect, :229
+                dir = fma3(nrm, -k, dn);                         // :359
+                if (FROM_HIT) { origin = fma3(hit.normal, .001f, hit.pos); }   // :221-222
+            }
+        }
+
+        if (active && path_ends) {
+            f3 result = mk3(1.0f - luma_expf(-direct.x), 1.0f - luma_expf(-direct.y),
+                            1.0f - luma_expf(-direct.z));        // :362, :57-70
+            if (gainf != 1.0f) { result = scale3(result, gainf); }   // :452
+            acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
+            s++;
+            bounce = 0;
+            direct = mk3(0.f, 0.f, 0.f);
+            dir = dir0;
+            origin = campos;
+        }
+    }
+
+    if (live) {
+        A.acc[0][local] = acc_r; A.acc[1][local] = acc_g; A.acc[2][local] = acc_b;
+        const float inv = 1.0f / A.frame_count_last;             // :460
+        int r = (int)((acc_r * inv) * 255.0f);                   // ::RGB, :44-55
+        int g = (int)((acc_g * inv) * 255.0f);
+        int b = (int)((acc_b * inv) * 255.0f);
+        if (A.flags & FLAG_CLAMP_PACK) {
+            r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
+        }
+        A.target[local] = ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;   // :461
+    }
+    wave_add_u64(A.counters, nrays);
+}
+
 // Per-sphere records for the scan, rebuilt when the scene or the camera position changes:
 // records[i]     = (camera.pos - centre, |camera.pos - centre|^2 - r^2)   (Renderer.cpp:244,:248)
 // records[n + i] = (centre, radius)
@@ -468,34 +746,46 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 {
     constexpr int tile_h = 64 / kTileW;
     const uint32_t rows = args.row_end - args.row_begin;
-    const size_t rec_bytes = scene_lds_bytes(args.n_spheres);
-    const size_t all_bytes = rec_bytes + (size_t)args.n_spheres * (sizeof(float4) + sizeof(float2));
-    const int scene = all_bytes <= kMaxSceneLdsBytes ? SCENE_LDS_ALL
-                    : rec_bytes <= kMaxSceneLdsBytes ? SCENE_LDS_RECORDS : SCENE_GLOBAL;
-    const size_t lds = scene == SCENE_LDS_ALL ? all_bytes : scene == SCENE_LDS_RECORDS ? rec_bytes : 0;
+    const uint32_t n = args.n_spheres;
     const bool noise = !(args.flags & FLAG_NOISE_OFF), from_hit = (args.flags & FLAG_ORIGIN_FROM_HIT) != 0;
-    // 8 workgroups of 4 waves fill a CU (32 waves) only while each needs <= 20 KiB of the
-    // 160 KiB LDS; beyond that switch to 16-wave workgroups (2 per CU up to 80 KiB, then 1).
-    const bool big_wg = lds > 20 * 1024;
-    const int wgx = wg_waves_x(big_wg ? 16 : 4), wgy = (big_wg ? 16 : 4) / wgx;
-    const dim3 grid((args.width + wgx * kTileW - 1) / (wgx * kTileW), (rows + wgy * tile_h - 1) / (wgy * tile_h));
-
     using kernel_t = void (*)(const RenderArgs);
-#define LUMA_K(W, S, N, F) render_kernel<kTileW, W, S, N, F>
-#define LUMA_KS(W, S) { { LUMA_K(W, S, false, false), LUMA_K(W, S, false, true) }, { LUMA_K(W, S, true, false), LUMA_K(W, S, true, true) } }
-    static const kernel_t table[2][3][2][2] = {
-        { LUMA_KS(4, 0), LUMA_KS(4, 1), LUMA_KS(4, 2) },
-        { LUMA_KS(16, 0), LUMA_KS(16, 1), LUMA_KS(16, 2) },
-    };
-#undef LUMA_KS
+
+    // Large scenes: sphere-parallel scan, records (padded to 256) in LDS.
+    const size_t sp_bytes = (size_t)((n + 255u) & ~255u) * 2u * sizeof(float4);
+    kernel_t k;
+    size_t lds;
+    int waves;
+    if (n >= kSphereParallelMin && sp_bytes <= kMaxSceneLdsBytes) {
+        // 8 workgroups of 4 waves fill a CU (32 waves) only while each needs <= 20 KiB of the
+        // 160 KiB LDS; beyond that use 16-wave workgroups (2 per CU up to 80 KiB, then 1).
+        lds = sp_bytes;
+        waves = lds > 20 * 1024 ? 16 : 4;
+#define LUMA_SP(W) { { render_kernel_sp<kTileW, W, false, false>, render_kernel_sp<kTileW, W, false, true> }, \
+                     { render_kernel_sp<kTileW, W, true, false>,  render_kernel_sp<kTileW, W, true, true> } }
+        static const kernel_t sp_table[2][2][2] = { LUMA_SP(4), LUMA_SP(16) };
+#undef LUMA_SP
+        k = sp_table[waves == 16][noise][from_hit];
+    } else {
+        // Small scenes: one lane = one ray, records + materials in LDS (56 B per sphere); scenes
+        // too large for LDS scan from global memory (wave-uniform addresses).
+        const size_t all_bytes = (size_t)n * (2 * sizeof(float4) + sizeof(float4) + sizeof(float2));
+        const int scene = all_bytes <= 20 * 1024 ? SCENE_LDS_ALL : SCENE_GLOBAL;
+        lds = scene == SCENE_LDS_ALL ? all_bytes : 0;
+        waves = 4;
+#define LUMA_K(S) { { render_kernel<kTileW, 4, S, false, false>, render_kernel<kTileW, 4, S, false, true> }, \
+                    { render_kernel<kTileW, 4, S, true, false>,  render_kernel<kTileW, 4, S, true, true> } }
+        static const kernel_t table[2][2][2] = { LUMA_K(SCENE_GLOBAL), LUMA_K(SCENE_LDS_ALL) };
 #undef LUMA_K
-    const kernel_t k = table[big_wg][scene][noise][from_hit];
+        k = table[scene == SCENE_LDS_ALL][noise][from_hit];
+    }
+    const int wgx = wg_waves_x(waves), wgy = waves / wgx;
+    const dim3 grid((args.width + wgx * kTileW - 1) / (wgx * kTileW), (rows + wgy * tile_h - 1) / (wgy * tile_h));
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { return e; }
     }
-    hipLaunchKernelGGL(k, grid, dim3(big_wg ? 1024 : 256), lds, stream, args);
+    hipLaunchKernelGGL(k, grid, dim3(waves * 64), lds, stream, args);
     return hipGetLastError();
 }
 

@@ -213,11 +213,16 @@ def test_posed_camera_render(abi, oracle):
     assert np.array_equal(acc.view(np.uint32), wacc.view(np.uint32))
 
 
-@pytest.mark.parametrize("n,W,H,spp", [(300, 96, 54, 2), (4096, 64, 36, 1), (6000, 48, 27, 1)])
-def test_synthetic_scene(abi, oracle, n, W, H, spp):
-    """Config #5's scene generator; n=4096 fills LDS (128 KiB of records), n=6000 exceeds it
-    and takes the global-memory scan."""
-    kw = dict(spp=spp, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+@pytest.mark.parametrize("n,W,H,spp,flags,paths", [
+    (300, 96, 54, 2, 0, 1), (4096, 64, 36, 1, 0, 1), (6000, 48, 27, 1, 0, 1),
+    (191, 40, 24, 2, 0, 1), (192, 40, 24, 2, 0, 1), (257, 33, 19, 2, 0, 2), (1000, 50, 30, 2, 2, 1),
+    (640, 37, 21, 1, 1, 1), (641, 37, 21, 2, 1 | 2, 0), (4864, 20, 12, 1, 0, 1), (4865, 20, 12, 1, 0, 1),
+])
+def test_synthetic_scene(abi, oracle, n, W, H, spp, flags, paths):
+    """Config #5's scene generator.  n < 192: ray-per-lane scan from LDS; 192 <= n <= 4864:
+    sphere-parallel scan (4-wave workgroups up to 640 spheres, 16-wave beyond; n=4096 fills
+    128 KiB of LDS); larger n: ray-per-lane scan from global memory."""
+    kw = dict(spp=spp, bounces=5, paths=paths, samples=1, mode=1, flags=flags, seed=SEED)
     got, acc, st = hip_render(abi, abi.synthetic_scene(n), abi.default_camera(W, H), W, H, **kw)
     want, wacc, ost = oracle.render(oracle.synthetic_scene(n), oracle.camera(W, H), oracle.make_params(W, H, **kw))
     assert_frames_equal(got, want, f"synthetic n={n}")
