@@ -530,8 +530,10 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         const float qnan = __builtin_nanf("");
         const float4 never = make_float4(qnan, qnan, qnan, qnan);
         for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
-            lds_rec[i] = (i < n) ? A.records[i] : never;
-            lds_rec[n_pad + i] = (i < n) ? A.records[n + i] : never;
+            float4 c = never, g = never;
+            if (i < n) { c = A.records[i]; g = A.records[n + i]; }
+            lds_rec[i] = c;
+            lds_rec[n_pad + i] = g;
         }
         __syncthreads();
     }
