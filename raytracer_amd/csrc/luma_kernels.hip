@@ -18,6 +18,8 @@
 #include <float.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace luma {
 
 #define LUMA_DEV __device__ __forceinline__
@@ -436,6 +438,23 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 // the loop (RNG, shading, accumulation) stays one lane = one pixel.
 // ---------------------------------------------------------------------------------
 
+// Wave-wide unsigned min, result uniform.  Four DPP steps make every row of 16 lanes uniform
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), then one lane per row is read back and
+// the four values are combined on the scalar unit.  Needs EXEC = all lanes.
+LUMA_DEV uint32_t wave_min_u32(uint32_t v)
+{
+    auto dpp = [](uint32_t x, auto ctrl) {
+        return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, decltype(ctrl)::value, 0xF, 0xF, false);
+    };
+    v = min(v, dpp(v, std::integral_constant<int, 0xB1>{}));    // quad_perm [1,0,3,2]
+    v = min(v, dpp(v, std::integral_constant<int, 0x4E>{}));    // quad_perm [2,3,0,1]
+    v = min(v, dpp(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror
+    v = min(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(r0, r1), min(r2, r3));
+}
+
 // Scan for lane `j`'s ray over records laid out [batch][lane] in LDS; n_pad is a multiple of
 // 256 and the padding records are NaN (never a candidate).  All 64 lanes must call this.
 template <bool CAM_ORIGIN>
@@ -477,15 +496,12 @@ LUMA_DEV unsigned long long wave_scan_one(const float4* __restrict__ rec, uint32
         }
     }
 
-    // lexicographic min of (t, index) over the wave; t > 0 so its bit pattern orders like the value
-    unsigned long long key = (best_i == 0xFFFFFFFFu)
-        ? ~0ull : (((unsigned long long)__builtin_bit_cast(uint32_t, best_t) << 32) | best_i);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long other = __shfl_xor(key, off, 64);
-        key = other < key ? other : key;
-    }
-    return key;
+    // Lexicographic min of (t, index) over the wave, in registers (DPP + readlane, no LDS round
+    // trips): first the smallest t (t > 0, so its bit pattern orders like its value), then the
+    // lowest index among the lanes that hold it.  0xFFFFFFFF in the index = no hit.
+    const uint32_t t_min = wave_min_u32(__builtin_bit_cast(uint32_t, best_t));
+    const uint32_t i_min = wave_min_u32(__builtin_bit_cast(uint32_t, best_t) == t_min ? best_i : 0xFFFFFFFFu);
+    return ((unsigned long long)t_min << 32) | i_min;
 }
 
 // Scans the ray of every lane with want == true (one after the other) and returns, in that
@@ -512,7 +528,7 @@ LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t
             oz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, origin.z), j));
         }
         const unsigned long long key = wave_scan_one<CAM_ORIGIN>(rec, n_pad, lane, ox, oy, oz, dx, dy, dz, aj);
-        if (lane == (uint32_t)j && key != ~0ull) {
+        if (lane == (uint32_t)j && (uint32_t)key != 0xFFFFFFFFu) {
             idx = (int)(uint32_t)key;
             t = __builtin_bit_cast(float, (uint32_t)(key >> 32));
         }
