@@ -68,7 +68,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config3")
     ap.add_argument("--emulate-world", type=int, default=0,
-                    help="profiling aid: render only band 0 of this many bands on one GPU")
+                    help="profiling aid: render only one band of this many bands on one GPU")
+    ap.add_argument("--emulate-rank", type=int, default=0, help="which band --emulate-world renders")
     a = ap.parse_args()
     global WIDTH, HEIGHT, SPP, BOUNCES
     wl = WORKLOADS[a.workload]
@@ -88,11 +89,16 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
 
-    y0, y1 = bands.band_rows(HEIGHT, a.emulate_world or world, rank)
+    nb, rb = (a.emulate_world or world), (a.emulate_rank if a.emulate_world else rank)
+    stripe = bands.stripe_rows_for(HEIGHT, nb)    # interleaved stripes even out sky / ground rows
+    y0, y1 = bands.band_rows(HEIGHT, nb, rb)
     ctx = abi.Context(local)
     ctx.set_scene(abi.synthetic_scene(wl["scene"], SEED) if wl["scene"] else abi.default_scene())
     ctx.set_camera(abi.default_camera(WIDTH, HEIGHT))
-    ctx.set_frame(WIDTH, HEIGHT, y0, y1)
+    if stripe:
+        ctx.set_frame_striped(WIDTH, HEIGHT, stripe, rb, nb)
+    else:
+        ctx.set_frame(WIDTH, HEIGHT, y0, y1)
     params = abi.make_params(WIDTH, HEIGHT, spp=SPP, bounces=BOUNCES, paths=PATHS, samples=SAMPLES,
                              mode=wl["mode"], flags=wl["flags"], seed=SEED)
     band = torch.empty((y1 - y0, WIDTH), dtype=torch.int32, device=dev)
@@ -101,6 +107,8 @@ def main():
 
     def step():
         ctx.render_device(params, band.data_ptr(), stream.cuda_stream)
+        if stripe:
+            return bands.gather_striped(band, HEIGHT, WIDTH, rank, world, stripe)
         return bands.gather_frame(band, HEIGHT, WIDTH, rank, world)
 
     def fence():
@@ -154,8 +162,9 @@ def main():
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"] + f", seed 0x{SEED:08X}"
-                                   + (f", band 0 of {a.emulate_world} only" if a.emulate_world else ""),
-                       "parallelism": f"{world} scanline band(s), RCCL gather to rank 0"},
+                                   + (f", band {a.emulate_rank} of {a.emulate_world} only" if a.emulate_world else ""),
+                       "parallelism": (f"{world} ranks, interleaved {stripe}-row stripes, RCCL gather to rank 0" if world > 1 and stripe
+                                       else f"{world} scanline band(s), RCCL gather to rank 0")},
             "frame_ms": ms_per_step,
             "msamples_per_s": WIDTH * (HEIGHT // (a.emulate_world or 1)) * SPP * a.steps / dt / 1e6,
             "rays_per_step": rays_per_step,

@@ -108,19 +108,27 @@ int luma_hip_set_camera(luma_ctx* ctx, const luma_camera* cam);
 int luma_hip_set_frame(luma_ctx* ctx, uint32_t width, uint32_t height,
                        uint32_t row_begin, uint32_t row_end);
 
+/* Same, for a band made of interleaved stripes: the context renders rows y with
+ * (y / stripe_rows) % n_ranks == rank, stored compactly in that order (stripe 0 of the rank,
+ * then its next stripe, ...).  height must be a multiple of stripe_rows * n_ranks.  Rows near
+ * the horizon cost more than sky rows, so interleaving evens the ranks out;
+ * the frame is still bit-identical to a one-device render.  No counterpart in the reference. */
+int luma_hip_set_frame_striped(luma_ctx* ctx, uint32_t width, uint32_t height, uint32_t stripe_rows,
+                               uint32_t rank, uint32_t n_ranks);
+
 /* The camera.moved branch, Renderer.cpp:377-390: frame_count = 1, accumulated_data = 0. */
 int luma_hip_reset(luma_ctx* ctx);
 
 /* ---- the render loop ----------------------------------------------------------- */
 
 /* Renderer::render_to (Renderer.cpp:366-471) for params->spp successive frames of the
- * context's band.  target_host receives the band's pixels, (row_end-row_begin)*width
+ * context's band.  target_host receives the band's pixels, rows*width
  * uint32 0x00RRGGBB, row-major (Renderer.cpp:461).  Synchronous.  stats may be NULL. */
 int luma_hip_render(luma_ctx* ctx, const luma_params* params, uint32_t* target_host,
                     luma_stats* stats);
 
 /* Same, but the band is left in device memory: target_dev is a device pointer to
- * (row_end-row_begin)*width uint32 (NULL: the context's own buffer, see
+ * rows*width uint32 (NULL: the context's own buffer, see
  * luma_hip_target_device).  Work is enqueued on `stream` (a hipStream_t; NULL = the
  * context's stream) and the call returns without waiting unless stats is non-NULL. */
 int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* target_dev,

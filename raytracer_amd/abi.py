@@ -18,7 +18,7 @@ FLAG_NOISE_OFF, FLAG_ORIGIN_FROM_HIT, FLAG_CLAMP_PACK, FLAG_NO_SHOW_DEPTH = 1, 2
 # every symbol include/luma_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [
     "luma_hip_create", "luma_hip_destroy", "luma_hip_set_scene", "luma_hip_set_camera",
-    "luma_hip_set_frame", "luma_hip_reset", "luma_hip_render", "luma_hip_render_device",
+    "luma_hip_set_frame", "luma_hip_set_frame_striped", "luma_hip_reset", "luma_hip_render", "luma_hip_render_device",
     "luma_hip_target_device", "luma_hip_read_accum", "luma_hip_frame_index",
     "luma_hip_generate_rays", "luma_camera_default", "luma_camera_from_pose",
     "luma_scene_default", "luma_scene_synthetic", "luma_hip_strerror", "luma_hip_last_error",
@@ -75,6 +75,7 @@ def lib():
         "luma_hip_set_scene": (C.c_int, [ctx, C.POINTER(Sphere), C.c_uint32]),
         "luma_hip_set_camera": (C.c_int, [ctx, C.POINTER(Camera)]),
         "luma_hip_set_frame": (C.c_int, [ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+        "luma_hip_set_frame_striped": (C.c_int, [ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
         "luma_hip_reset": (C.c_int, [ctx]),
         "luma_hip_render": (C.c_int, [ctx, C.POINTER(Params), u32p, C.POINTER(Stats)]),
         "luma_hip_render_device": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
@@ -179,6 +180,12 @@ class Context:
         row_end = height if row_end is None else row_end
         check(lib().luma_hip_set_frame(self._h, width, height, row_begin, row_end), "luma_hip_set_frame")
         self.width, self.height, self.row_begin, self.row_end = width, height, row_begin, row_end
+
+    def set_frame_striped(self, width, height, stripe_rows, rank, n_ranks):
+        check(lib().luma_hip_set_frame_striped(self._h, width, height, stripe_rows, rank, n_ranks),
+              "luma_hip_set_frame_striped")
+        self.width, self.height = width, height
+        self.row_begin, self.row_end = 0, height // n_ranks      # rows == row_end - row_begin
 
     def reset(self):
         check(lib().luma_hip_reset(self._h), "luma_hip_reset")

@@ -86,17 +86,19 @@ struct luma_ctx {
     bool have_camera = false;
 
     // frame / band
-    uint32_t width = 0, height = 0, row_begin = 0, row_end = 0;
+    uint32_t width = 0, height = 0, row_begin = 0, rows = 0, stripe = 1, pitch = 1;   // see RenderArgs
     float* d_acc = nullptr;        // 3 planes of rows*width
     uint32_t* d_target = nullptr;  // rows*width
     uint32_t frame_index = 0;
     bool have_frame = false;
+    float* d_split = nullptr;      // parked frames of split renders (luma_kernels.hip, SPLIT), grown on demand
+    size_t split_bytes = 0;
 
     unsigned long long* d_counters = nullptr;  // rays traced since luma_hip_create, in kCounterSlots partial sums
     unsigned long long* h_counters = nullptr;  // pinned
     unsigned long long rays_reported = 0;      // part of that total already handed out in a luma_stats
 
-    size_t band_pixels() const { return static_cast<size_t>(row_end - row_begin) * width; }
+    size_t band_pixels() const { return static_cast<size_t>(rows) * width; }
 };
 
 namespace {
@@ -132,7 +134,9 @@ luma::RenderArgs make_args(const luma_ctx* ctx, const luma_params* p, uint32_t* 
     a.width = ctx->width;
     a.height = ctx->height;
     a.row_begin = ctx->row_begin;
-    a.row_end = ctx->row_end;
+    a.rows = ctx->rows;
+    a.stripe = ctx->stripe;
+    a.pitch = ctx->pitch;
     if (p) {
         a.bounces = p->bounces;
         a.paths = p->paths;
@@ -159,6 +163,8 @@ luma::RenderArgs make_args(const luma_ctx* ctx, const luma_params* p, uint32_t* 
     a.acc[2] = ctx->d_acc ? ctx->d_acc + 2 * plane : nullptr;
     a.target = target_dev;
     a.counters = ctx->d_counters;
+    a.split = 1;
+    a.split_scratch = nullptr;
     return a;
 }
 
@@ -175,7 +181,21 @@ int refresh_records(luma_ctx* ctx, hipStream_t stream)
 int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hipStream_t stream)
 {
     if (int rc = refresh_records(ctx, stream)) { return rc; }
-    const luma::RenderArgs args = make_args(ctx, p, target_dev);
+    luma::RenderArgs args = make_args(ctx, p, target_dev);
+    args.split = luma::choose_split(ctx->band_pixels(), p->spp, ctx->n_spheres);
+    if (args.split > 1) {
+        const size_t need = static_cast<size_t>(p->spp - p->spp / args.split) * 3u * ctx->band_pixels() * sizeof(float);
+        if (need > (size_t(2) << 30)) {
+            args.split = 1;                                      // not worth 2 GiB of scratch
+        } else if (need > ctx->split_bytes) {
+            LUMA_HIP_TRY(hipStreamSynchronize(stream));
+            free_dev(ctx->d_split);
+            ctx->split_bytes = 0;
+            LUMA_HIP_TRY(hipMalloc(&ctx->d_split, need));
+            ctx->split_bytes = need;
+        }
+        args.split_scratch = ctx->d_split;
+    }
     LUMA_HIP_TRY(hipEventRecord(ctx->ev_begin, stream));
     LUMA_HIP_TRY(luma::launch_render(args, stream));
     LUMA_HIP_TRY(hipEventRecord(ctx->ev_end, stream));
@@ -258,7 +278,7 @@ void luma_hip_destroy(luma_ctx* ctx)
     if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
     free_dev(ctx->d_cx); free_dev(ctx->d_cy); free_dev(ctx->d_cz); free_dev(ctx->d_rad);
     free_dev(ctx->d_mat0); free_dev(ctx->d_mat1); free_dev(ctx->d_records);
-    free_dev(ctx->d_acc); free_dev(ctx->d_target); free_dev(ctx->d_counters);
+    free_dev(ctx->d_acc); free_dev(ctx->d_target); free_dev(ctx->d_counters); free_dev(ctx->d_split);
     if (ctx->h_counters) { (void)hipHostFree(ctx->h_counters); }
     if (ctx->ev_begin) { (void)hipEventDestroy(ctx->ev_begin); }
     if (ctx->ev_end) { (void)hipEventDestroy(ctx->ev_end); }
@@ -324,6 +344,29 @@ int luma_hip_set_camera(luma_ctx* ctx, const luma_camera* cam)
     return LUMA_OK;
 }
 
+namespace {
+
+int set_frame_geometry(luma_ctx* ctx, const char* who, uint32_t width, uint32_t height,
+                       uint32_t row_begin, uint32_t rows, uint32_t stripe, uint32_t pitch)
+{
+    if (static_cast<uint64_t>(width) * height > 0x7FFFFFFFull) { return fail(LUMA_E_ARG, who, "frame larger than 2^31 pixels"); }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    free_dev(ctx->d_acc);
+    free_dev(ctx->d_target);
+    ctx->have_frame = false;
+    ctx->width = width; ctx->height = height;
+    ctx->row_begin = row_begin; ctx->rows = rows; ctx->stripe = stripe; ctx->pitch = pitch;
+    const size_t px = ctx->band_pixels();
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_acc, 3 * px * sizeof(float)));
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_target, px * sizeof(uint32_t)));
+    ctx->have_frame = true;
+    return luma_hip_reset(ctx);
+}
+
+}  // namespace
+
 int luma_hip_set_frame(luma_ctx* ctx, uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end)
 {
     if (!ctx) { return fail(LUMA_E_ARG, "luma_hip_set_frame", "null context"); }
@@ -331,22 +374,24 @@ int luma_hip_set_frame(luma_ctx* ctx, uint32_t width, uint32_t height, uint32_t 
     if (row_begin >= row_end || row_end > height) {
         return fail(LUMA_E_ARG, "luma_hip_set_frame", "need row_begin < row_end <= height");
     }
-    if (static_cast<uint64_t>(width) * height > 0x7FFFFFFFull) {
-        return fail(LUMA_E_ARG, "luma_hip_set_frame", "frame larger than 2^31 pixels");
+    const uint32_t rows = row_end - row_begin;
+    return set_frame_geometry(ctx, "luma_hip_set_frame", width, height, row_begin, rows, rows, rows);
+}
+
+int luma_hip_set_frame_striped(luma_ctx* ctx, uint32_t width, uint32_t height, uint32_t stripe_rows,
+                               uint32_t rank, uint32_t n_ranks)
+{
+    const char* who = "luma_hip_set_frame_striped";
+    if (!ctx) { return fail(LUMA_E_ARG, who, "null context"); }
+    if (width == 0 || height == 0 || stripe_rows == 0 || n_ranks == 0 || rank >= n_ranks) {
+        return fail(LUMA_E_ARG, who, "zero size or rank out of range");
     }
-    DeviceScope scope(ctx->device);
-    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_set_frame", "hipSetDevice failed"); }
-    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
-    free_dev(ctx->d_acc);
-    free_dev(ctx->d_target);
-    ctx->have_frame = false;
-    ctx->width = width; ctx->height = height;
-    ctx->row_begin = row_begin; ctx->row_end = row_end;
-    const size_t px = ctx->band_pixels();
-    LUMA_HIP_TRY(hipMalloc(&ctx->d_acc, 3 * px * sizeof(float)));
-    LUMA_HIP_TRY(hipMalloc(&ctx->d_target, px * sizeof(uint32_t)));
-    ctx->have_frame = true;
-    return luma_hip_reset(ctx);
+    const uint64_t pitch = static_cast<uint64_t>(stripe_rows) * n_ranks;
+    if (pitch > height || height % pitch != 0) {
+        return fail(LUMA_E_ARG, who, "height must be a multiple of stripe_rows * n_ranks");
+    }
+    const uint32_t rows = static_cast<uint32_t>(height / pitch) * stripe_rows;
+    return set_frame_geometry(ctx, who, width, height, rank * stripe_rows, rows, stripe_rows, static_cast<uint32_t>(pitch));
 }
 
 int luma_hip_reset(luma_ctx* ctx)

@@ -29,8 +29,10 @@ static constexpr uint32_t kCounterStride = 8;
 
 // Passed by value as the kernel argument (lands in SGPRs / the kernarg segment).
 struct RenderArgs {
-    // frame geometry: this launch renders rows [row_begin,row_end) of width x height
-    uint32_t width, height, row_begin, row_end;
+    // frame geometry: this launch renders `rows` rows of a width x height frame; local row yl is
+    // global row  row_begin + (yl / stripe) * pitch + yl % stripe.  A contiguous band is one
+    // stripe (stripe == rows); interleaved stripes have pitch == stripe * number of ranks.
+    uint32_t width, height, row_begin, rows, stripe, pitch;
     // luma::Options snapshot (arguments.h:35-41)
     uint32_t bounces, paths, mode, flags, spp;
     uint32_t frame_index;       // frames accumulated before this launch
@@ -51,10 +53,15 @@ struct RenderArgs {
     // outputs (band-local)
     float*    acc[3];           // accumulation planes r, g, b
     uint32_t* target;           // 0x00RRGGBB
+    // frame splitting (ray-per-lane kernel): lanes per pixel (1, 2 or 4) and the planes where
+    // lanes 1.. park their frames: (spp - spp/split) x 3 x band pixels floats
+    uint32_t  split;
+    float*    split_scratch;
     unsigned long long* counters;  // kCounterSlots x kCounterStride: rays traced, summed by the host
 };
 
 size_t     scene_lds_bytes(uint32_t n_spheres);
+uint32_t   choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres);
 hipError_t launch_prepare_records(const float* cx, const float* cy, const float* cz, const float* rad,
                                   uint32_t n, const float pos[3], float4* records, hipStream_t stream);
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);

@@ -112,6 +112,12 @@ LUMA_DEV void apply4(const float* m, float v0, float v1, float v2, float v3, flo
     }
 }
 
+// Local row of the band -> row of the frame (contiguous band or interleaved stripes).
+LUMA_DEV uint32_t global_row(const RenderArgs& A, uint32_t yl)
+{
+    return A.row_begin + (yl / A.stripe) * A.pitch + (yl % A.stripe);
+}
+
 // One entry of Camera::recompute_rays, Camera.cpp:193-213, in registers.
 LUMA_DEV f3 camera_ray(const RenderArgs& A, uint32_t x, uint32_t y)
 {
@@ -252,13 +258,21 @@ LUMA_DEV void wave_add_u64(unsigned long long* slots, uint32_t v)
 // Workgroups are WAVES waves arranged wg_waves_x(WAVES) wide: 4 waves = 2x2 (32x8 pixels),
 // 16 waves = 4x4 (64x16 pixels).  The large shape is for scenes whose LDS image limits a CU to
 // one or two workgroups: 16 waves keep 4 per SIMD to cover the LDS latency of the scan.
-constexpr int wg_waves_x(int waves) { return waves == 16 ? 4 : 2; }
+constexpr int wg_waves_x(int waves) { return waves == 16 ? 4 : waves >= 2 ? 2 : 1; }
 
 // Where the scene lives during the launch: scan records (32 B/sphere) and, when they also
 // fit, the material vectors (24 B/sphere) are staged into LDS once per workgroup.
 enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 
-template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT>
+//
+// SPLIT (1, 2 or 4) spreads the frames of one pixel over SPLIT lanes of the same workgroup when
+// the band has too few pixels to fill the GPU (8 GPUs x 1080p leave 259k pixels per GPU for
+// 524k thread slots, and one lane needs ~0.4 ms for 64 frames whatever the band size).  Lane k of
+// a pixel renders frames [k*spp/SPLIT, (k+1)*spp/SPLIT).  Lane 0 adds its frames to the
+// accumulator as before; the others park each frame's colour in a global scratch plane, and
+// after a workgroup barrier lane 0 adds those in frame order, so the float sum is still the
+// reference's ((acc + f0) + f1) + ... (Renderer.cpp:457-458), bit for bit.
+template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT>
 __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 {
     // [0,n): camera-origin records; [n,2n): general records; then mat0[n] (float4), mat1[n] (float2)
@@ -284,26 +298,32 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
         __syncthreads();
     }
 
-    // lane -> pixel inside the wave tile; wave -> tile inside the workgroup (WGX x WGY waves)
+    // lane -> pixel inside the wave tile; wave -> (frame block k, tile inside the workgroup)
     constexpr int TILE_H = 64 / TILE_W;
-    constexpr int WGX = wg_waves_x(WAVES), WGY = WAVES / WGX;
+    constexpr int WPK = WAVES / SPLIT;                           // waves per frame block
+    constexpr int WGX = wg_waves_x(WPK), WGY = WPK / WGX;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * (WGX * TILE_W) + (wave % WGX) * TILE_W + (lane % TILE_W);
-    const uint32_t yl = blockIdx.y * (WGY * TILE_H) + (wave / WGX) * TILE_H + (lane / TILE_W);
-    const uint32_t y = A.row_begin + yl;
-    const bool live = (x < A.width) && (y < A.row_end);
+    const uint32_t k = wave / WPK, wv = wave % WPK;
+    const uint32_t x = blockIdx.x * (WGX * TILE_W) + (wv % WGX) * TILE_W + (lane % TILE_W);
+    const uint32_t yl = blockIdx.y * (WGY * TILE_H) + (wv / WGX) * TILE_H + (lane / TILE_W);
+    const uint32_t y = global_row(A, yl);
+    const bool live = (x < A.width) && (yl < A.rows);
 
+    const uint32_t pixel = y * A.width + x;                      // global index: RNG is band independent (:399)
+    const uint32_t local = yl * A.width + x;                     // index into the band's planes
+    const size_t npix = (size_t)A.rows * A.width;
+    const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
+    const uint32_t slots = 2u + A.paths;
+    const bool pathtrace = A.mode == MODE_PATHTRACE;
     uint32_t nrays = 0;
-    if (live) {
-        const uint32_t pixel = y * A.width + x;                  // global index: RNG is band independent (:399)
-        const uint32_t local = yl * A.width + x;                 // index into the band's planes
-        const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
-        const uint32_t slots = 2u + A.paths;
-        const bool pathtrace = A.mode == MODE_PATHTRACE;
 
-        const f3 dir0 = camera_ray(A, x, y);                     // camera.rays[index], :413
-
-        // DOF pre-pass, :416-432.  Noise free, so it is the same for every frame of the call.
+    // DOF pre-pass, :416-432.  Noise free, so it is the same for every frame of the call; with
+    // SPLIT > 1 lane 0 of the pixel traces it and hands blur and gain to the others through LDS.
+    __shared__ float2 dof_shared[SPLIT > 1 ? WPK * 64 : 1];
+    f3 dir0 = mk3(0.f, 0.f, -1.f);
+    float blur = 0.f, gainf = 1.f;
+    if (live) { dir0 = camera_ray(A, x, y); }                    // camera.rays[index], :413
+    if (live && k == 0) {
         float t0;
         const int h0 = scan_spheres<true, (SCENE == SCENE_GLOBAL)>(rec_cam, n, campos, dir0, t0);
         nrays++;
@@ -311,19 +331,29 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
         const float dd = depth - A.focus_depth;                  // :425
         const float x2 = dd * dd, x4 = x2 * x2, x8 = x4 * x4, x10 = x8 * x2;
         const float focus = 1.0f - luma_expf(-x10);              // :427
-        const float blur = fma_(focus, 4.5f, 0.5f);              // :429-432
-        const float gainf = (A.show_depth && (focus < .5f)) ? 1.2f : 1.0f;   // :448-452
+        blur = fma_(focus, 4.5f, 0.5f);                          // :429-432
+        gainf = (A.show_depth && (focus < .5f)) ? 1.2f : 1.0f;   // :448-452
+        if (SPLIT > 1) { dof_shared[wv * 64 + lane] = make_float2(blur, gainf); }
+    }
+    if (SPLIT > 1) {
+        __syncthreads();
+        if (live && k != 0) { const float2 v = dof_shared[wv * 64 + lane]; blur = v.x; gainf = v.y; }
+    }
 
-        float acc_r = A.acc[0][local], acc_g = A.acc[1][local], acc_b = A.acc[2][local];
+    // bounces == 0: the loop at :300 never runs, every sample adds tonemap(0) * gain = +0.
+    const uint32_t spp_all = A.bounces ? A.spp : 0u;
+    const uint32_t s_first = k * spp_all / SPLIT, spp = (k + 1u) * spp_all / SPLIT;   // this lane's frames
+    const uint32_t s_park = spp_all / SPLIT;                     // frames >= s_park go through the scratch planes
+    float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
+
+    if (live) {
+        if (k == 0) { acc_r = A.acc[0][local]; acc_g = A.acc[1][local]; acc_b = A.acc[2][local]; }
 
         // per-lane path state
-        uint32_t s = 0, bounce = 0;
+        uint32_t s = s_first, bounce = 0;
         f3 direct = mk3(0.f, 0.f, 0.f);
         f3 dir = dir0;                                           // :293
         f3 origin = campos;                                      // :294, :303
-
-        // bounces == 0: the loop at :300 never runs, every sample adds tonemap(0) * gain = +0.
-        const uint32_t spp = A.bounces ? A.spp : 0u;
 
         while (s < spp) {
             const uint32_t sample = A.frame_index + s;
@@ -397,7 +427,12 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
                 f3 result = mk3(1.0f - luma_expf(-direct.x), 1.0f - luma_expf(-direct.y),
                                 1.0f - luma_expf(-direct.z));    // :362, :57-70
                 if (gainf != 1.0f) { result = scale3(result, gainf); }   // :452
-                acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
+                if (SPLIT == 1 || k == 0) {
+                    acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
+                } else {
+                    float* park = A.split_scratch + (size_t)(s - s_park) * 3u * npix + local;
+                    park[0] = result.x; park[npix] = result.y; park[2 * npix] = result.z;
+                }
                 s++;
                 bounce = 0;
                 direct = mk3(0.f, 0.f, 0.f);
@@ -405,7 +440,17 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
                 origin = campos;
             }
         }
+    }
 
+    if (SPLIT > 1) { __syncthreads(); }                          // parked frames are visible to the workgroup
+
+    if (live && k == 0) {
+        if (SPLIT > 1) {
+            for (uint32_t f = s_park; f < spp_all; f++) {        // the other lanes' frames, in frame order
+                const float* park = A.split_scratch + (size_t)(f - s_park) * 3u * npix + local;
+                acc_r += park[0]; acc_g += park[npix]; acc_b += park[2 * npix];   // :457-458
+            }
+        }
         A.acc[0][local] = acc_r; A.acc[1][local] = acc_g; A.acc[2][local] = acc_b;
 
         const float inv = 1.0f / A.frame_count_last;             // :460
@@ -561,8 +606,8 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t x = blockIdx.x * (WGX * TILE_W) + (wave % WGX) * TILE_W + (lane % TILE_W);
     const uint32_t yl = blockIdx.y * (WGY * TILE_H) + (wave / WGX) * TILE_H + (lane / TILE_W);
-    const uint32_t y = A.row_begin + yl;
-    const bool live = (x < A.width) && (y < A.row_end);
+    const uint32_t y = global_row(A, yl);
+    const bool live = (x < A.width) && (yl < A.rows);
 
     const uint32_t pixel = y * A.width + x;                      // global index (:399); unused when !live
     const uint32_t local = yl * A.width + x;
@@ -736,11 +781,25 @@ __global__ void generate_rays_kernel(const RenderArgs A, float* __restrict__ ray
 {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t yl = blockIdx.y;
-    const uint32_t y = A.row_begin + yl;
-    if (x >= A.width || y >= A.row_end) { return; }
+    const uint32_t y = global_row(A, yl);
+    if (x >= A.width || yl >= A.rows) { return; }
     const f3 d = camera_ray(A, x, y);
     float* o = rays + 3 * ((size_t)yl * A.width + x);
     o[0] = d.x; o[1] = d.y; o[2] = d.z;
+}
+
+// How many lanes share one pixel's frames in the ray-per-lane kernel (see SPLIT there): enough to
+// put ~400k threads on the GPU, never more than the frames of the call.
+uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres)
+{
+    const bool sphere_parallel = n_spheres >= kSphereParallelMin
+        && (size_t)((n_spheres + 255u) & ~255u) * 2u * sizeof(float4) <= kMaxSceneLdsBytes;
+    if (sphere_parallel) { return 1; }
+    // measured on MI355X, 1080p x 64 spp bands: 2 lanes per pixel win below ~800k pixels
+    // (0.80 -> 0.70 ms at 518k, 0.56 -> 0.41 ms at 259k), 4 only on very small bands
+    uint32_t split = band_pixels >= 800000 ? 1u : band_pixels >= 100000 ? 2u : 4u;
+    while (split > spp) { split >>= 1; }
+    return split ? split : 1u;
 }
 
 // ---------------------------------------------------------------------------------
@@ -763,7 +822,7 @@ hipError_t launch_prepare_records(const float* cx, const float* cy, const float*
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 {
     constexpr int tile_h = 64 / kTileW;
-    const uint32_t rows = args.row_end - args.row_begin;
+    const uint32_t rows = args.rows;
     const uint32_t n = args.n_spheres;
     const bool noise = !(args.flags & FLAG_NOISE_OFF), from_hit = (args.flags & FLAG_ORIGIN_FROM_HIT) != 0;
     using kernel_t = void (*)(const RenderArgs);
@@ -772,7 +831,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     const size_t sp_bytes = (size_t)((n + 255u) & ~255u) * 2u * sizeof(float4);
     kernel_t k;
     size_t lds;
-    int waves;
+    int waves, split = 1;
     if (n >= kSphereParallelMin && sp_bytes <= kMaxSceneLdsBytes) {
         // 8 workgroups of 4 waves fill a CU (32 waves) only while each needs <= 20 KiB of the
         // 160 KiB LDS; beyond that use 16-wave workgroups (2 per CU up to 80 KiB, then 1).
@@ -790,13 +849,19 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         const int scene = all_bytes <= 20 * 1024 ? SCENE_LDS_ALL : SCENE_GLOBAL;
         lds = scene == SCENE_LDS_ALL ? all_bytes : 0;
         waves = 4;
-#define LUMA_K(S) { { render_kernel<kTileW, 4, S, false, false>, render_kernel<kTileW, 4, S, false, true> }, \
-                    { render_kernel<kTileW, 4, S, true, false>,  render_kernel<kTileW, 4, S, true, true> } }
-        static const kernel_t table[2][2][2] = { LUMA_K(SCENE_GLOBAL), LUMA_K(SCENE_LDS_ALL) };
+        split = args.split;
+#define LUMA_K(S, P) { { render_kernel<kTileW, 4, S, false, false, P>, render_kernel<kTileW, 4, S, false, true, P> }, \
+                       { render_kernel<kTileW, 4, S, true, false, P>,  render_kernel<kTileW, 4, S, true, true, P> } }
+        static const kernel_t table[3][2][2][2] = {
+            { LUMA_K(SCENE_GLOBAL, 1), LUMA_K(SCENE_LDS_ALL, 1) },
+            { LUMA_K(SCENE_GLOBAL, 2), LUMA_K(SCENE_LDS_ALL, 2) },
+            { LUMA_K(SCENE_GLOBAL, 4), LUMA_K(SCENE_LDS_ALL, 4) },
+        };
 #undef LUMA_K
-        k = table[scene == SCENE_LDS_ALL][noise][from_hit];
+        k = table[split == 4 ? 2 : split == 2 ? 1 : 0][scene == SCENE_LDS_ALL][noise][from_hit];
     }
-    const int wgx = wg_waves_x(waves), wgy = waves / wgx;
+    const int wpk = waves / split;                               // waves that tile pixels (the rest split frames)
+    const int wgx = wg_waves_x(wpk), wgy = wpk / wgx;
     const dim3 grid((args.width + wgx * kTileW - 1) / (wgx * kTileW), (rows + wgy * tile_h - 1) / (wgy * tile_h));
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
@@ -809,7 +874,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 
 hipError_t launch_generate_rays(const RenderArgs& args, float* rays, hipStream_t stream)
 {
-    const uint32_t rows = args.row_end - args.row_begin;
+    const uint32_t rows = args.rows;
     const dim3 grid((args.width + 255) / 256, rows);
     hipLaunchKernelGGL(generate_rays_kernel, grid, dim3(256), 0, stream, args, rays);
     return hipGetLastError();

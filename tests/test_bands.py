@@ -28,6 +28,63 @@ def test_band_rows_partition():
         bands.band_rows(100, 2, 2)
 
 
+def test_striped_rows_partition():
+    for H, N, S in [(1080, 8, 15), (1080, 4, 15), (2160, 8, 15), (120, 2, 15), (64, 4, 4)]:
+        rows = [bands.striped_rows(H, N, r, S) for r in range(N)]
+        assert sorted(y for rr in rows for y in rr) == list(range(H))
+        assert all(len(rr) == H // N for rr in rows)
+        assert rows[1][:S] == list(range(S, 2 * S)) and rows[0][S:2 * S] == list(range(N * S, N * S + S))
+    assert bands.stripe_rows_for(1080, 8) == 15 and bands.stripe_rows_for(1080, 1) == 0
+    assert bands.stripe_rows_for(1000, 8) == 0
+    with pytest.raises(ValueError):
+        bands.striped_rows(100, 8, 0, 15)
+
+
+def _striped_worker(rank, world, port, H, W, stripe, q):
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_binding as ob
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows = bands.striped_rows(H, world, rank, stripe)
+        p = ob.make_params(W, H, spp=2, bounces=5, mode=1, seed=0x4C554D41)
+        r = ob.Renderer(ob.default_scene(), ob.camera(W, H), W, H)
+        for y0 in rows[::stripe]:
+            r.render(p, rows=(y0, y0 + stripe))
+        band = torch.from_numpy(r.target[rows].astype(np.int64).astype(np.int32).copy())
+        frame = bands.gather_striped(band, H, W, rank, world, stripe)
+        if rank == 0:
+            q.put(frame.numpy().astype(np.uint32))
+        else:
+            assert frame is None
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_striped_gather_equals_full_frame():
+    import torch.multiprocessing as mp
+    import oracle_binding as ob
+    W, H, stripe = 40, 24, 3
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_striped_worker, args=(r, 2, port, H, W, stripe, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    frame = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full, _, _ = ob.render(ob.default_scene(), ob.camera(W, H), ob.make_params(W, H, spp=2, bounces=5, mode=1, seed=0x4C554D41))
+    assert np.array_equal(frame, full)
+
+
 def _worker(rank, world, port, H, W, q):
     import sys
     import torch

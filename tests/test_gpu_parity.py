@@ -276,6 +276,36 @@ def test_bands_equal_full_frame(abi, oracle, nbands):
     assert rays == fst.rays
 
 
+@pytest.mark.parametrize("W,H,stripe,n,scene_n", [(96, 48, 3, 4, 0), (64, 120, 15, 8, 0), (50, 32, 4, 2, 300)])
+def test_interleaved_stripes_equal_full_frame(abi, oracle, W, H, stripe, n, scene_n):
+    """luma_hip_set_frame_striped: rank r renders rows with (y / stripe) % n == r; the stripes put
+    back in order are bit-identical to the one-device frame (and to the oracle)."""
+    from raytracer_amd import bands
+    kw = dict(spp=3, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    scene = abi.synthetic_scene(scene_n) if scene_n else abi.default_scene()
+    oscene = oracle.synthetic_scene(scene_n) if scene_n else oracle.default_scene()
+    want, wacc, ost = oracle.render(oscene, oracle.camera(W, H), oracle.make_params(W, H, **kw))
+    frame = np.zeros((H, W), dtype=np.uint32)
+    for r in range(n):
+        with abi.Context(0) as ctx:
+            ctx.set_scene(scene)
+            ctx.set_camera(abi.default_camera(W, H))
+            ctx.set_frame_striped(W, H, stripe, r, n)
+            band, _ = ctx.render(abi.make_params(W, H, **kw))
+            acc = ctx.read_accum()
+            rays = ctx.generate_rays()
+        rows = bands.striped_rows(H, n, r, stripe)
+        assert band.shape == (H // n, W)
+        frame[rows] = band
+        assert np.array_equal(acc.view(np.uint32), wacc[rows].view(np.uint32))
+        assert np.array_equal(rays, oracle.camera_rays(oracle.camera(W, H), W, H)[rows])
+    assert_frames_equal(frame, want, "striped bands")
+    with abi.Context(0) as ctx:
+        with pytest.raises(abi.LumaError) as e:
+            ctx.set_frame_striped(64, 100, 15, 0, 8)
+        assert e.value.code == abi.E_ARG
+
+
 # ---- device-resident target (what bench.py times) ------------------------------------
 
 def test_render_device_matches_host_target(abi):
