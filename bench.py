@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="profiling aid: render only one band of this many bands on one GPU")
     ap.add_argument("--emulate-rank", type=int, default=0, help="which band --emulate-world renders")
+    ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks "
+                         "(bands are gathered through host memory; not a measurement)")
     a = ap.parse_args()
     global WIDTH, HEIGHT, SPP, BOUNCES
     wl = WORKLOADS[a.workload]
@@ -84,10 +87,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    rehearsal = a.dist_backend == "gloo"
+    if rehearsal:
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+    red_dev = torch.device("cpu") if rehearsal else dev
 
     nb, rb = (a.emulate_world or world), (a.emulate_rank if a.emulate_world else rank)
     stripe = bands.stripe_rows_for(HEIGHT, nb)    # interleaved stripes even out sky / ground rows
@@ -101,17 +111,31 @@ def main():
         ctx.set_frame(WIDTH, HEIGHT, y0, y1)
     params = abi.make_params(WIDTH, HEIGHT, spp=SPP, bounces=BOUNCES, paths=PATHS, samples=SAMPLES,
                              mode=wl["mode"], flags=wl["flags"], seed=SEED)
-    band = torch.empty((y1 - y0, WIDTH), dtype=torch.int32, device=dev)
     stream = torch.cuda.Stream(device=dev)          # a real (non-null) stream: kernels, gather and events share it
     torch.cuda.set_stream(stream)
+    pipelined = world > 1 and (stripe or HEIGHT % world == 0) and not rehearsal
+    pg = bands.PipelinedGather(HEIGHT, WIDTH, rank, world, stripe, dev, rows=y1 - y0) if pipelined or world == 1 else None
+    band = pg.bufs[0] if pg else torch.empty((y1 - y0, WIDTH), dtype=torch.int32, device=dev)
+    nstep = [0]
 
     def step():
+        # one frame: render this rank's band, hand it to the gather.  With several ranks the
+        # gather of frame i overlaps the render of frame i+1 (two band buffers).
+        if pg:
+            buf = pg.acquire(nstep[0])
+            ctx.render_device(params, buf.data_ptr(), stream.cuda_stream)
+            pg.submit(nstep[0])
+            nstep[0] += 1
+            return None
         ctx.render_device(params, band.data_ptr(), stream.cuda_stream)
+        send = band.cpu() if rehearsal else band
         if stripe:
-            return bands.gather_striped(band, HEIGHT, WIDTH, rank, world, stripe)
-        return bands.gather_frame(band, HEIGHT, WIDTH, rank, world)
+            return bands.gather_striped(send, HEIGHT, WIDTH, rank, world, stripe)
+        return bands.gather_frame(send, HEIGHT, WIDTH, rank, world)
 
     def fence():
+        if pg:
+            pg.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -119,6 +143,7 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    fence()
     ctx.render_device(params, band.data_ptr(), stream.cuda_stream, want_stats=True)   # drain the ray counter
     fence()
     t0 = time.perf_counter()
@@ -141,7 +166,7 @@ def main():
     rays_per_launch = st.rays / (a.steps + 1)      # a.steps timed launches + the stats launch itself
     tests_per_launch = st.sphere_tests / (a.steps + 1)
 
-    t = torch.tensor([dt, rays_per_launch, tests_per_launch, kernel_ms], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt, rays_per_launch, tests_per_launch, kernel_ms], dtype=torch.float64, device=red_dev)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -160,7 +185,7 @@ def main():
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, not a measurement)" if rehearsal and world > 1 else ""),
             "config": {"workload": wl["name"] + f", seed 0x{SEED:08X}"
                                    + (f", band {a.emulate_rank} of {a.emulate_world} only" if a.emulate_world else ""),
                        "parallelism": (f"{world} ranks, interleaved {stripe}-row stripes, RCCL gather to rank 0" if world > 1 and stripe

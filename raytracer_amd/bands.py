@@ -77,3 +77,57 @@ def gather_frame(band, height, width, rank, world_size, dst=0):
         return frame
     dist.send(band, dst=dst)
     return None
+
+
+class PipelinedGather:
+    """Two band buffers per rank so that the gather of frame i (RCCL, its own stream) overlaps
+    the render of frame i+1.  Usage per frame:  b = pg.acquire(i); <render into b>; pg.submit(i).
+    acquire() makes the current stream wait for the gather that last used that buffer, so the
+    renderer never overwrites a band that is still being sent.  finish() drains and, on dst,
+    returns the last frame in row order."""
+
+    def __init__(self, height, width, rank, world_size, stripe, device, rows=None, dst=0):
+        import torch
+        self.h, self.w, self.rank, self.world, self.stripe, self.dst = height, width, rank, world_size, stripe, dst
+        if world_size > 1 and height % world_size:
+            raise ValueError("pipelined gather needs equal bands")
+        rows = height // world_size if rows is None else rows
+        self.bufs = [torch.empty((rows, width), dtype=torch.int32, device=device) for _ in range(2)]
+        self.gathered = ([torch.empty((world_size, rows, width), dtype=torch.int32, device=device) for _ in range(2)]
+                         if rank == dst and world_size > 1 else [None, None])
+        self.works = [None, None]
+        self.last = None
+
+    def acquire(self, i):
+        b = i & 1
+        if self.works[b] is not None:
+            self.works[b].wait()
+            self.works[b] = None
+        return self.bufs[b]
+
+    def submit(self, i):
+        import torch.distributed as dist
+        b = i & 1
+        self.last = b
+        if self.world == 1:
+            return
+        g = self.gathered[b]
+        self.works[b] = dist.gather(self.bufs[b], gather_list=list(g.unbind(0)) if g is not None else None,
+                                    dst=self.dst, async_op=True)
+
+    def finish(self):
+        for b in (0, 1):
+            if self.works[b] is not None:
+                self.works[b].wait()
+                self.works[b] = None
+        if self.last is None:
+            return None
+        if self.world == 1:
+            return self.bufs[self.last]
+        if self.rank != self.dst:
+            return None
+        g = self.gathered[self.last]
+        if self.stripe:
+            q = self.h // (self.stripe * self.world)
+            return g.view(self.world, q, self.stripe, self.w).permute(1, 0, 2, 3).reshape(self.h, self.w)
+        return g.reshape(self.h, self.w)

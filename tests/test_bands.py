@@ -65,6 +65,47 @@ def _striped_worker(rank, world, port, H, W, stripe, q):
         dist.destroy_process_group()
 
 
+def _pipelined_worker(rank, world, port, H, W, stripe, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rows = bands.striped_rows(H, world, rank, stripe) if stripe else list(range(*bands.band_rows(H, world, rank)))
+        pg = bands.PipelinedGather(H, W, rank, world, stripe, torch.device("cpu"))
+        for i in range(5):                       # frame i holds the value 1000*i + row
+            buf = pg.acquire(i)
+            buf.copy_(torch.tensor([[1000 * i + y] * W for y in rows], dtype=torch.int32))
+            pg.submit(i)
+        frame = pg.finish()
+        if rank == 0:
+            q.put(frame.numpy().copy())
+        else:
+            assert frame is None
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stripe", [0, 3])
+def test_pipelined_gather_two_ranks(stripe):
+    import torch.multiprocessing as mp
+    W, H = 8, 24
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, H, W, stripe, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    frame = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.array_equal(frame, np.array([[4000 + y] * W for y in range(H)], dtype=np.int32))
+
+
 def test_two_rank_striped_gather_equals_full_frame():
     import torch.multiprocessing as mp
     import oracle_binding as ob
