@@ -36,6 +36,16 @@ FLOP_PER_TEST, FLOP_PER_RAY = 17.0, 64.0          # SURVEY.md 8d / BASELINE.md s
 PEAK_FP32_VALU_TFLOPS = 157.3                     # MI355X_MICROARCH.md, "Peak FP32 (vector)"
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/r01/traffic.json: FETCH_SIZE x2 for gfx950 + WRITE_SIZE), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
+            return json.load(f).get(workload, {}).get("corrected_bytes")
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(seconds_target=12.0):
     """The CPU oracle (a port: the reference itself cannot be built) on ONE host core, the
     reference's execution model (Renderer.cpp:392), on a bounded sample of the same
@@ -195,7 +205,10 @@ def main():
             "rays_per_step": rays_per_step,
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
+                         "traffic": measured_traffic(a.workload) if world == 1 and not a.emulate_world else None,
+                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01/traffic.json)",
+                         "algorithmic_bytes": 28 * WIDTH * (y1 - y0),
                          "kernel": "luma::render_kernel", "flop_model": "17*sphere_tests + 64*rays (SURVEY 8d)"},
         }
         if not a.no_cpu_baseline and world == 1 and a.workload == "config3" and not a.emulate_world:
