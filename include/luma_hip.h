@@ -130,7 +130,9 @@ int luma_hip_render(luma_ctx* ctx, const luma_params* params, uint32_t* target_h
 /* Same, but the band is left in device memory: target_dev is a device pointer to
  * rows*width uint32 (NULL: the context's own buffer, see
  * luma_hip_target_device).  Work is enqueued on `stream` (a hipStream_t; NULL = the
- * context's stream) and the call returns without waiting unless stats is non-NULL. */
+ * context's stream) and the call returns without waiting unless stats is non-NULL.  Calls on
+ * one context are ordered: a call on a different stream than the previous one first waits for
+ * the device (the accumulation planes are read-modify-write state). */
 int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* target_dev,
                            void* stream, luma_stats* stats);
 

@@ -91,6 +91,8 @@ struct luma_ctx {
     uint32_t* d_target = nullptr;  // rows*width
     uint32_t frame_index = 0;
     bool have_frame = false;
+    hipStream_t last_stream = nullptr;   // stream of the latest render call (the planes are RMW state)
+    bool rendered = false;
     float* d_split = nullptr;      // parked frames of split renders (luma_kernels.hip, SPLIT), grown on demand
     size_t split_bytes = 0;
 
@@ -177,9 +179,18 @@ int refresh_records(luma_ctx* ctx, hipStream_t stream)
     return LUMA_OK;
 }
 
+// The accumulation planes are read-modify-write state: work touching them on a different
+// stream than the previous render call must not overtake it.
+int order_after_previous(luma_ctx* ctx, hipStream_t stream)
+{
+    if (ctx->rendered && ctx->last_stream != stream) { LUMA_HIP_TRY(hipDeviceSynchronize()); }
+    return LUMA_OK;
+}
+
 // Enqueue one render call on `stream`.  Events bracket the render kernel only.
 int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hipStream_t stream)
 {
+    if (int rc = order_after_previous(ctx, stream)) { return rc; }
     if (int rc = refresh_records(ctx, stream)) { return rc; }
     luma::RenderArgs args = make_args(ctx, p, target_dev);
     args.split = luma::choose_split(ctx->band_pixels(), p->spp, ctx->n_spheres);
@@ -188,7 +199,7 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
         if (need > (size_t(2) << 30)) {
             args.split = 1;                                      // not worth 2 GiB of scratch
         } else if (need > ctx->split_bytes) {
-            LUMA_HIP_TRY(hipStreamSynchronize(stream));
+            LUMA_HIP_TRY(hipDeviceSynchronize());
             free_dev(ctx->d_split);
             ctx->split_bytes = 0;
             LUMA_HIP_TRY(hipMalloc(&ctx->d_split, need));
@@ -200,6 +211,8 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
     LUMA_HIP_TRY(luma::launch_render(args, stream));
     LUMA_HIP_TRY(hipEventRecord(ctx->ev_end, stream));
     ctx->frame_index += p->spp;
+    ctx->last_stream = stream;
+    ctx->rendered = true;
     return LUMA_OK;
 }
 
@@ -275,7 +288,7 @@ void luma_hip_destroy(luma_ctx* ctx)
 {
     if (!ctx) { return; }
     DeviceScope scope(ctx->device);
-    if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); }
+    (void)hipDeviceSynchronize();   // launches may be in flight on the caller's streams too
     free_dev(ctx->d_cx); free_dev(ctx->d_cy); free_dev(ctx->d_cz); free_dev(ctx->d_rad);
     free_dev(ctx->d_mat0); free_dev(ctx->d_mat1); free_dev(ctx->d_records);
     free_dev(ctx->d_acc); free_dev(ctx->d_target); free_dev(ctx->d_counters); free_dev(ctx->d_split);
@@ -293,19 +306,25 @@ int luma_hip_set_scene(luma_ctx* ctx, const luma_sphere* spheres, uint32_t n)
     if (n > (1u << 24)) { return fail(LUMA_E_ARG, "luma_hip_set_scene", "too many spheres (max 2^24)"); }
     DeviceScope scope(ctx->device);
     if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_set_scene", "hipSetDevice failed"); }
-    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // launches given a caller's stream (luma_hip_render_device) may still read the old arrays
+    LUMA_HIP_TRY(hipDeviceSynchronize());
 
     free_dev(ctx->d_cx); free_dev(ctx->d_cy); free_dev(ctx->d_cz); free_dev(ctx->d_rad);
     free_dev(ctx->d_mat0); free_dev(ctx->d_mat1); free_dev(ctx->d_records);
-    ctx->n_spheres = n;
-    ctx->have_scene = true;
+    ctx->n_spheres = 0;
+    ctx->have_scene = false;          // until every array below is in place
     ctx->records_stale = true;
-    if (n == 0) { return LUMA_OK; }   // empty scene: every ray misses (Renderer.cpp:276)
+    if (n == 0) { ctx->have_scene = true; return LUMA_OK; }   // empty scene: every ray misses (Renderer.cpp:276)
 
     // AoS (renderer.h:23-36) -> SoA geometry + packed material vectors
-    std::vector<float> cx(n), cy(n), cz(n), rad(n);
-    std::vector<float4> m0(n);
-    std::vector<float2> m1(n);
+    std::vector<float> cx, cy, cz, rad;
+    std::vector<float4> m0;
+    std::vector<float2> m1;
+    try {
+        cx.resize(n); cy.resize(n); cz.resize(n); rad.resize(n); m0.resize(n); m1.resize(n);
+    } catch (...) {
+        return fail(LUMA_E_NOMEM, "luma_hip_set_scene", "host allocation failed");
+    }
     for (uint32_t i = 0; i < n; i++) {
         const luma_sphere& s = spheres[i];
         cx[i] = s.cx; cy[i] = s.cy; cz[i] = s.cz; rad[i] = s.radius;
@@ -326,6 +345,8 @@ int luma_hip_set_scene(luma_ctx* ctx, const luma_sphere* spheres, uint32_t n)
     LUMA_HIP_TRY(hipMemcpy(ctx->d_rad, rad.data(), fb, hipMemcpyHostToDevice));
     LUMA_HIP_TRY(hipMemcpy(ctx->d_mat0, m0.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     LUMA_HIP_TRY(hipMemcpy(ctx->d_mat1, m1.data(), n * sizeof(float2), hipMemcpyHostToDevice));
+    ctx->n_spheres = n;
+    ctx->have_scene = true;
     return LUMA_OK;
 }
 
@@ -334,9 +355,9 @@ int luma_hip_set_camera(luma_ctx* ctx, const luma_camera* cam)
     if (!ctx || !cam) { return fail(LUMA_E_ARG, "luma_hip_set_camera", "null argument"); }
     DeviceScope scope(ctx->device);
     if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_set_camera", "hipSetDevice failed"); }
-    // the scan records embed camera.pos; in-flight launches hold the old ones
-    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (!ctx->have_camera || std::memcmp(ctx->camera.pos, cam->pos, sizeof cam->pos) != 0) {
+        // the scan records embed camera.pos; launches in flight (on any stream) read the old ones
+        LUMA_HIP_TRY(hipDeviceSynchronize());
         ctx->records_stale = true;
     }
     ctx->camera = *cam;
@@ -352,7 +373,7 @@ int set_frame_geometry(luma_ctx* ctx, const char* who, uint32_t width, uint32_t 
     if (static_cast<uint64_t>(width) * height > 0x7FFFFFFFull) { return fail(LUMA_E_ARG, who, "frame larger than 2^31 pixels"); }
     DeviceScope scope(ctx->device);
     if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
-    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    LUMA_HIP_TRY(hipDeviceSynchronize());   // also covers launches on a caller's stream
     free_dev(ctx->d_acc);
     free_dev(ctx->d_target);
     ctx->have_frame = false;
@@ -400,11 +421,13 @@ int luma_hip_reset(luma_ctx* ctx)
     if (!ctx->have_frame) { return fail(LUMA_E_STATE, "luma_hip_reset", "luma_hip_set_frame not called"); }
     DeviceScope scope(ctx->device);
     if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_reset", "hipSetDevice failed"); }
+    if (int rc = order_after_previous(ctx, ctx->stream)) { return rc; }
     const size_t px = ctx->band_pixels();
     LUMA_HIP_TRY(hipMemsetAsync(ctx->d_acc, 0, 3 * px * sizeof(float), ctx->stream));      // Renderer.cpp:381-387
     LUMA_HIP_TRY(hipMemsetAsync(ctx->d_target, 0, px * sizeof(uint32_t), ctx->stream));
     LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->frame_index = 0;                                                                  // Renderer.cpp:379
+    ctx->last_stream = ctx->stream;
     return LUMA_OK;
 }
 
@@ -461,6 +484,7 @@ int luma_hip_read_accum(luma_ctx* ctx, float* rgb_host)
     if (!ctx->have_frame) { return fail(LUMA_E_STATE, "luma_hip_read_accum", "luma_hip_set_frame not called"); }
     DeviceScope scope(ctx->device);
     if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_read_accum", "hipSetDevice failed"); }
+    if (int rc = order_after_previous(ctx, ctx->stream)) { return rc; }
     LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const size_t px = ctx->band_pixels();
     std::vector<float> planes;
