@@ -46,28 +46,48 @@ def measured_traffic(workload):
         return None
 
 
-def cpu_baseline(seconds_target=12.0):
-    """The CPU oracle (a port: the reference itself cannot be built) on ONE host core, the
-    reference's execution model (Renderer.cpp:392), on a bounded sample of the same
-    workload: 4-row groups spread evenly over the 1080 rows, all 64 spp."""
+def cpu_baseline(seconds_target=10.0, threads_all=None):
+    """The CPU oracle (a port: the reference itself cannot be built) on a bounded sample of the
+    same workload: 4-row groups spread evenly over the 1080 rows, all 64 spp.  The headline figure
+    is ONE host core, the reference's execution model (Renderer.cpp:392); `all_cores` repeats it
+    with one oracle thread per core of this process's CPU share (rows are independent)."""
+    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
     cam, scene = ob.camera(WIDTH, HEIGHT), ob.default_scene()
     p = ob.make_params(WIDTH, HEIGHT, spp=SPP, bounces=BOUNCES, paths=PATHS, samples=SAMPLES, mode=1, seed=SEED)
-    r = ob.Renderer(scene, cam, WIDTH, HEIGHT)
+
+    def one_group(y0):
+        r = ob.Renderer(scene, cam, WIDTH, HEIGHT)   # own buffers and counters per call
+        r.render(p, rows=(y0, y0 + 4))
+        return r.stats.rays
+
     groups = list(range(0, HEIGHT, 8))             # 135 groups of 4 rows
     t0 = time.perf_counter()
-    rows = 0
+    rows, rays = 0, 0
     for y0 in groups:
-        r.render(p, rows=(y0, y0 + 4))
+        rays += one_group(y0)
         rows += 4
         if time.perf_counter() - t0 > seconds_target:
             break
     dt = time.perf_counter() - t0
-    return {"value": r.stats.rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
-            "sample": f"{rows} of {HEIGHT} rows (4-row groups every 8 rows, time-capped) x {WIDTH} px x {SPP} spp, "
-                      f"{r.stats.rays} rays in {dt:.2f} s",
-            "msamples_per_s": rows * WIDTH * SPP / dt / 1e6}
+    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+           "sample": f"{rows} of {HEIGHT} rows (4-row groups every 8 rows, time-capped) x {WIDTH} px x {SPP} spp, "
+                     f"{rays} rays in {dt:.2f} s",
+           "msamples_per_s": rows * WIDTH * SPP / dt / 1e6}
+    try:
+        ncores = threads_all or min(len(os.sched_getaffinity(0)), int(os.environ.get("OMP_NUM_THREADS", "16")))
+    except (AttributeError, ValueError):
+        ncores = 1
+    if ncores > 1:
+        sample = groups[4::8][:ncores * 2]          # 2 groups per thread: about seconds_target / 4 of wall time
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(ncores) as pool:
+            rays_mt = sum(pool.map(one_group, sample))
+        dt = time.perf_counter() - t0
+        out["all_cores"] = {"value": rays_mt / dt / 1e6, "unit": "Mrays/s", "cores": ncores,
+                            "sample": f"{4 * len(sample)} rows over {ncores} threads, {rays_mt} rays in {dt:.2f} s"}
+    return out
 
 
 def main():

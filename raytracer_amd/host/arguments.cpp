@@ -70,6 +70,7 @@ void Arguments::parse(const std::vector<std::string>& arguments)
             _options.seed = s; return true; } } },
         { "frames",  { "frame count", number_into(_options.frames) } },
         { "flags",   { "flags", number_into(_options.flags) } },
+        { "shm",     { "shared-memory name", [](const std::string& v) { if (v.empty()) { return false; } _options.shm = v; return true; } } },
         { "output",  { "output path", [](const std::string& v) { if (v.empty()) { return false; } _options.output = v; return true; } } },
     };
 

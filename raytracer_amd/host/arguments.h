@@ -25,6 +25,7 @@ struct Options {
     std::uint32_t frames = 1;       // headless: frames to accumulate before writing the image
     std::uint32_t flags = 0;        // LUMA_FLAG_* (0 == reference behaviour)
     std::string output = "output.ppm";
+    std::string shm;                // headless: POSIX shared-memory name that receives every frame ("" = off)
 };
 
 extern Options _options;

@@ -5,8 +5,14 @@
 //
 //   luma_headless --backend hip --width=1920 --height=1080 --mode=pathtrace --bounces=5
 //                 --samples=1 --paths=1 --frames=64 --output=frame.ppm
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <chrono>
 #include <cstdio>
+#include <cstring>
+#include <cerrno>
 #include <memory>
 #include <string>
 #include <vector>
@@ -15,6 +21,38 @@
 #include "image.h"
 #include "log.h"
 #include "renderer.h"
+
+namespace {
+
+// The reference's HEADLESS context publishes every frame in a named shared-memory block for an
+// external viewer (CreateFileMapping "LumaFramebuffer", main.cpp:249-256, memcpy at :35-41).
+// POSIX equivalent: shm_open + mmap; the object is left in place at exit so the last frame
+// stays readable.
+class FrameShare {
+public:
+    FrameShare(const std::string& name, std::size_t bytes) : bytes_(bytes)
+    {
+        if (name.empty()) { return; }
+        const std::string path = name[0] == '/' ? name : "/" + name;
+        const int fd = shm_open(path.c_str(), O_CREAT | O_RDWR, 0644);
+        if (fd < 0 || ftruncate(fd, static_cast<off_t>(bytes)) != 0) {
+            std::printf("failed to create the memory-mapped resource: %s\n", std::strerror(errno));   // main.cpp:252
+            if (fd >= 0) { close(fd); }
+            return;
+        }
+        void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p != MAP_FAILED) { view_ = p; }
+    }
+    ~FrameShare() { if (view_) { munmap(view_, bytes_); } }
+    void publish(const std::uint32_t* frame) { if (view_) { std::memcpy(view_, frame, bytes_); } }
+
+private:
+    void* view_ = nullptr;
+    std::size_t bytes_;
+};
+
+}  // namespace
 
 int main(int argc, char** argv)
 {
@@ -40,6 +78,8 @@ int main(int argc, char** argv)
     const std::size_t pixels = static_cast<std::size_t>(luma::_options.width) * luma::_options.height;
     std::unique_ptr<std::uint32_t[]> framebuffer(new std::uint32_t[pixels]());
 
+    FrameShare share(luma::_options.shm, pixels * sizeof(std::uint32_t));
+
     auto then = std::chrono::high_resolution_clock::now();
     double kernel_ms = 0.0;
     unsigned long long rays = 0;
@@ -48,6 +88,7 @@ int main(int argc, char** argv)
         const auto now = std::chrono::high_resolution_clock::now();
         const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(now - then).count();
         then = now;
+        share.publish(framebuffer.get());                            // main.cpp:274
         kernel_ms += renderer.last_stats().kernel_ms;
         rays += renderer.last_stats().rays;
         std::printf("[DELIVERED FRAME]:%u:%lld\n", frame, static_cast<long long>(ms));

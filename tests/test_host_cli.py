@@ -71,3 +71,23 @@ def test_headless_bmp(tmp_path, oracle):
     ref = tmp_path / "oracle.bmp"
     assert oracle.export_bmp(want, str(ref)) == 0
     assert out.read_bytes() == ref.read_bytes()
+
+
+@pytest.mark.gpu
+def test_headless_shared_memory_frame(tmp_path, oracle):
+    """--shm publishes every frame in a POSIX shared-memory block, the Linux form of the
+    reference's LumaFramebuffer mapping (main.cpp:249-256, :274)."""
+    name = f"luma_test_fb_{os.getpid()}"
+    path = os.path.join("/dev/shm", name)
+    out = tmp_path / "f.ppm"
+    try:
+        r = run("--backend=hip", "--width=48", "--height=20", "--mode=raytrace", "--bounces=1", "--frames=2", "--flags=1",
+                f"--shm={name}", f"--output={out}")
+        assert r.returncode == 0, r.stdout + r.stderr
+        want, _, _ = oracle.render(oracle.default_scene(), oracle.camera(48, 20),
+                                   oracle.make_params(48, 20, spp=2, bounces=1, mode=0, flags=1))
+        got = np.fromfile(path, dtype=np.uint32).reshape(20, 48)
+        assert np.array_equal(got, want)
+    finally:
+        if os.path.exists(path):
+            os.remove(path)
