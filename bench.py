@@ -80,7 +80,7 @@ def cpu_baseline(seconds_target=10.0, threads_all=None):
     except (AttributeError, ValueError):
         ncores = 1
     if ncores > 1:
-        sample = groups[4::8][:ncores * 2]          # 2 groups per thread: about seconds_target / 4 of wall time
+        sample = groups[1::2][:ncores * 6]          # up to 6 four-row groups per thread, a second or so of wall time
         t0 = time.perf_counter()
         with ThreadPoolExecutor(ncores) as pool:
             rays_mt = sum(pool.map(one_group, sample))
