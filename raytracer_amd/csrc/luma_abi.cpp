@@ -18,6 +18,7 @@ namespace {
 thread_local char g_last_error[512] = "";
 
 constexpr size_t kCounterBytes = sizeof(unsigned long long) * luma::kCounterSlots * luma::kCounterStride;
+constexpr size_t kCounterAlloc = kCounterBytes + 64;   // + one line for the sphere-parallel kernel's tile counter
 
 int fail(int code, const char* what, const char* detail)
 {
@@ -165,6 +166,7 @@ luma::RenderArgs make_args(const luma_ctx* ctx, const luma_params* p, uint32_t* 
     a.acc[2] = ctx->d_acc ? ctx->d_acc + 2 * plane : nullptr;
     a.target = target_dev;
     a.counters = ctx->d_counters;
+    a.tile_counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_counters) + kCounterBytes);
     a.split = 1;
     a.split_scratch = nullptr;
     return a;
@@ -206,6 +208,9 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
             ctx->split_bytes = need;
         }
         args.split_scratch = ctx->d_split;
+    }
+    if (luma::sphere_parallel_scene(ctx->n_spheres)) {
+        LUMA_HIP_TRY(hipMemsetAsync(args.tile_counter, 0, sizeof(uint32_t), stream));
     }
     LUMA_HIP_TRY(hipEventRecord(ctx->ev_begin, stream));
     LUMA_HIP_TRY(luma::launch_render(args, stream));
@@ -277,9 +282,9 @@ int luma_hip_create(luma_ctx** out, int device_id)
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { return bail(e, "hipStreamCreate"); }
     if ((e = hipEventCreate(&ctx->ev_begin)) != hipSuccess) { return bail(e, "hipEventCreate"); }
     if ((e = hipEventCreate(&ctx->ev_end)) != hipSuccess) { return bail(e, "hipEventCreate"); }
-    if ((e = hipMalloc(&ctx->d_counters, kCounterBytes)) != hipSuccess) { return bail(e, "hipMalloc(counters)"); }
+    if ((e = hipMalloc(&ctx->d_counters, kCounterAlloc)) != hipSuccess) { return bail(e, "hipMalloc(counters)"); }
     if ((e = hipHostMalloc(&ctx->h_counters, kCounterBytes)) != hipSuccess) { return bail(e, "hipHostMalloc(counters)"); }
-    if ((e = hipMemset(ctx->d_counters, 0, kCounterBytes)) != hipSuccess) { return bail(e, "hipMemset(counters)"); }
+    if ((e = hipMemset(ctx->d_counters, 0, kCounterAlloc)) != hipSuccess) { return bail(e, "hipMemset(counters)"); }
     *out = ctx;
     return LUMA_OK;
 }

@@ -57,10 +57,12 @@ struct RenderArgs {
     // lanes 1.. park their frames: (spp - spp/split) x 3 x band pixels floats
     uint32_t  split;
     float*    split_scratch;
+    uint32_t* tile_counter;        // sphere-parallel kernel: next wave tile, zeroed before every launch
     unsigned long long* counters;  // kCounterSlots x kCounterStride: rays traced, summed by the host
 };
 
 size_t     scene_lds_bytes(uint32_t n_spheres);
+bool       sphere_parallel_scene(uint32_t n_spheres);
 uint32_t   choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres);
 hipError_t launch_prepare_records(const float* cx, const float* cy, const float* cz, const float* rad,
                                   uint32_t n, const float pos[3], float4* records, hipStream_t stream);

@@ -18,6 +18,7 @@
 #include <float.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 namespace luma {
@@ -601,20 +602,32 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     const float4* rec_cam = lds_rec;
     const float4* rec_gen = lds_rec + n_pad;
 
+    // Persistent waves: the grid is one resident set of workgroups (the 128-KiB record image
+    // allows one 16-wave workgroup per CU), and each wave pulls 16x4-pixel tiles from a global
+    // counter until none are left.  The records are staged once per workgroup instead of once
+    // per 1024 pixels, and a CU never idles waiting for the slowest wave of a workgroup.
     constexpr int TILE_H = 64 / TILE_W;
-    constexpr int WGX = wg_waves_x(WAVES), WGY = WAVES / WGX;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t x = blockIdx.x * (WGX * TILE_W) + (wave % WGX) * TILE_W + (lane % TILE_W);
-    const uint32_t yl = blockIdx.y * (WGY * TILE_H) + (wave / WGX) * TILE_H + (lane / TILE_W);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tiles_x = (A.width + TILE_W - 1) / TILE_W, tiles_y = (A.rows + TILE_H - 1) / TILE_H;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
+    const uint32_t slots = 2u + A.paths;
+    const bool pathtrace = A.mode == MODE_PATHTRACE;
+    uint32_t nrays = 0;
+
+  for (;;) {
+    uint32_t tile = 0;
+    if (lane == 0) { tile = atomicAdd(A.tile_counter, 1u); }
+    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
+    if (tile >= n_tiles) { break; }                              // every wave reaches this: the counter only grows
+
+    const uint32_t x = (tile % tiles_x) * TILE_W + (lane % TILE_W);
+    const uint32_t yl = (tile / tiles_x) * TILE_H + (lane / TILE_W);
     const uint32_t y = global_row(A, yl);
     const bool live = (x < A.width) && (yl < A.rows);
 
     const uint32_t pixel = y * A.width + x;                      // global index (:399); unused when !live
     const uint32_t local = yl * A.width + x;
-    const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
-    const uint32_t slots = 2u + A.paths;
-    const bool pathtrace = A.mode == MODE_PATHTRACE;
-    uint32_t nrays = 0;
 
     const f3 dir0 = camera_ray(A, live ? x : 0u, live ? y : 0u); // camera.rays[index], :413
 
@@ -757,6 +770,8 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         }
         A.target[local] = ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;   // :461
     }
+  }  // next tile
+
     wave_add_u64(A.counters, nrays);
 }
 
@@ -790,11 +805,15 @@ __global__ void generate_rays_kernel(const RenderArgs A, float* __restrict__ ray
 
 // How many lanes share one pixel's frames in the ray-per-lane kernel (see SPLIT there): enough to
 // put ~400k threads on the GPU, never more than the frames of the call.
+bool sphere_parallel_scene(uint32_t n_spheres)
+{
+    return n_spheres >= kSphereParallelMin
+        && (size_t)((n_spheres + 255u) & ~255u) * 2u * sizeof(float4) <= kMaxSceneLdsBytes;
+}
+
 uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres)
 {
-    const bool sphere_parallel = n_spheres >= kSphereParallelMin
-        && (size_t)((n_spheres + 255u) & ~255u) * 2u * sizeof(float4) <= kMaxSceneLdsBytes;
-    if (sphere_parallel) { return 1; }
+    if (sphere_parallel_scene(n_spheres)) { return 1; }
     // measured on MI355X, 1080p x 64 spp bands: 2 lanes per pixel win below ~800k pixels
     // (0.80 -> 0.70 ms at 518k, 0.56 -> 0.41 ms at 259k), 4 only on very small bands
     uint32_t split = band_pixels >= 800000 ? 1u : band_pixels >= 100000 ? 2u : 4u;
@@ -832,7 +851,8 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     kernel_t k;
     size_t lds;
     int waves, split = 1;
-    if (n >= kSphereParallelMin && sp_bytes <= kMaxSceneLdsBytes) {
+    const bool sphere_parallel = sphere_parallel_scene(n);
+    if (sphere_parallel) {
         // 8 workgroups of 4 waves fill a CU (32 waves) only while each needs <= 20 KiB of the
         // 160 KiB LDS; beyond that use 16-wave workgroups (2 per CU up to 80 KiB, then 1).
         lds = sp_bytes;
@@ -862,7 +882,18 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     }
     const int wpk = waves / split;                               // waves that tile pixels (the rest split frames)
     const int wgx = wg_waves_x(wpk), wgy = wpk / wgx;
-    const dim3 grid((args.width + wgx * kTileW - 1) / (wgx * kTileW), (rows + wgy * tile_h - 1) / (wgy * tile_h));
+    dim3 grid((args.width + wgx * kTileW - 1) / (wgx * kTileW), (rows + wgy * tile_h - 1) / (wgy * tile_h));
+    if (sphere_parallel) {
+        // persistent waves: one resident set of workgroups, tiles handed out by a counter
+        int cus = 256;
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
+        const size_t by_lds = (160u * 1024u) / (lds ? lds : 1);
+        const size_t per_cu = std::max<size_t>(1, std::min<size_t>(32 / waves, by_lds));
+        const uint32_t n_tiles = ((args.width + kTileW - 1) / kTileW) * ((rows + tile_h - 1) / tile_h);
+        const size_t want = (n_tiles + waves - 1) / waves;
+        grid = dim3((unsigned)std::max<size_t>(1, std::min<size_t>(want, per_cu * (size_t)cus)), 1);
+    }
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
