@@ -40,7 +40,9 @@ enum {
     LUMA_FLAG_NOISE_OFF       = 1u, /* no direction / roughness noise, no RNG (the reference has no such path: Renderer.cpp:302) */
     LUMA_FLAG_ORIGIN_FROM_HIT = 2u, /* bounce rays start at the hit point + .001 normal (Renderer.cpp:221-222) instead of camera.pos (:303) */
     LUMA_FLAG_CLAMP_PACK      = 4u, /* clamp channels to [0,255] before packing (Renderer.cpp:44-55 does not) */
-    LUMA_FLAG_NO_SHOW_DEPTH   = 8u  /* skip the in-focus x1.2 (Renderer.cpp:448-454) regardless of camera.show_depth */
+    LUMA_FLAG_NO_SHOW_DEPTH   = 8u, /* skip the in-focus x1.2 (Renderer.cpp:448-454) regardless of camera.show_depth */
+    LUMA_FLAG_PACK_RGBA8      = 16u /* target bytes R,G,B,255 (0xFFBBGGRR) instead of ::RGB's 0x00RRGGBB (Renderer.cpp:44-55);
+                                       same truncation and OR-combining, so combine with CLAMP_PACK for display use */
 };
 
 typedef struct luma_ctx luma_ctx;

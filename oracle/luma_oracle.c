@@ -157,6 +157,13 @@ uint32_t lo_pack_rgb(const float in[3], uint32_t flags)
         b = b < 0 ? 0 : (b > 255 ? 255 : b);
     }
     uint32_t out = 0;
+    if (flags & LO_FLAG_PACK_RGBA8) {
+        out |= (uint32_t)r << 0;
+        out |= (uint32_t)g << 8;
+        out |= (uint32_t)b << 16;
+        out |= 0xFF000000u;
+        return out;
+    }
     out |= (uint32_t)r << 16;
     out |= (uint32_t)g << 8;
     out |= (uint32_t)b << 0;

@@ -12,6 +12,7 @@ enum : uint32_t {
     FLAG_ORIGIN_FROM_HIT = 2u,
     FLAG_CLAMP_PACK      = 4u,
     FLAG_NO_SHOW_DEPTH   = 8u,
+    FLAG_PACK_RGBA8      = 16u,
 };
 enum : uint32_t { MODE_RAYTRACE = 0, MODE_PATHTRACE = 1 };
 

@@ -273,6 +273,15 @@ enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 // accumulator as before; the others park each frame's colour in a global scratch plane, and
 // after a workgroup barrier lane 0 adds those in frame order, so the float sum is still the
 // reference's ((acc + f0) + f1) + ... (Renderer.cpp:457-458), bit for bit.
+// ::RGB's shift-and-OR (Renderer.cpp:48-52), or the byte order R,G,B,255 for PACK_RGBA8.
+__device__ __forceinline__ uint32_t pack_pixel(int r, int g, int b, uint32_t flags)
+{
+    if (flags & FLAG_PACK_RGBA8) {
+        return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | 0xFF000000u;
+    }
+    return ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;
+}
+
 template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT>
 __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 {
@@ -461,7 +470,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
         if (A.flags & FLAG_CLAMP_PACK) {
             r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
         }
-        A.target[local] = ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;   // :461
+        A.target[local] = pack_pixel(r, g, b, A.flags);          // :461
     }
 
     wave_add_u64(A.counters, nrays);
@@ -768,7 +777,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         if (A.flags & FLAG_CLAMP_PACK) {
             r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
         }
-        A.target[local] = ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;   // :461
+        A.target[local] = pack_pixel(r, g, b, A.flags);          // :461
     }
   }  // next tile
 

@@ -15,6 +15,7 @@ public:
     void shadow_from(std::uint32_t* data) noexcept;          // alias the caller's frame (image.cpp:25-28)
     void export_to_ppm(const std::string& filepath) noexcept;
     void export_to_bmp(const std::string& filepath) noexcept;
+    void export_to_pnm(const std::string& filepath) noexcept;    // binary P6, row-major (not in the reference)
 
 private:
     const std::int32_t _width, _height;

@@ -102,6 +102,7 @@ int main(int argc, char** argv)
     image.shadow_from(framebuffer.get());
     const std::string& out = luma::_options.output;
     if (out.size() > 4 && out.compare(out.size() - 4, 4, ".bmp") == 0) { image.export_to_bmp(out); }
+    else if (out.size() > 4 && out.compare(out.size() - 4, 4, ".pnm") == 0) { image.export_to_pnm(out); }
     else { image.export_to_ppm(out); }
     luma::log("wrote `" + out + "`");
     return 0;

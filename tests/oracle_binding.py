@@ -16,6 +16,7 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "libluma_oracle.so")
 FLAG_NOISE_OFF = 1
 FLAG_ORIGIN_FROM_HIT = 2
 FLAG_CLAMP_PACK = 4
+FLAG_PACK_RGBA8 = 16
 FLAG_NO_SHOW_DEPTH = 8
 
 MODE_RAYTRACE = 0

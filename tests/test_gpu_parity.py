@@ -246,7 +246,7 @@ def test_against_committed_golden_frames(abi):
 
 # ---- flags, scenes, edge cases -------------------------------------------------------
 
-@pytest.mark.parametrize("flags", [2, 4, 8, 2 | 4 | 8, 1 | 2])
+@pytest.mark.parametrize("flags", [2, 4, 8, 2 | 4 | 8, 1 | 2, 16, 4 | 16])
 def test_flags(abi, oracle, flags):
     W, H = 120, 68
     kw = dict(spp=3, bounces=5, paths=2, samples=1, mode=1, flags=flags, seed=7)
@@ -254,6 +254,21 @@ def test_flags(abi, oracle, flags):
     want, wacc, _ = oracle.render(oracle.default_scene(), oracle.camera(W, H), oracle.make_params(W, H, **kw))
     assert_frames_equal(got, want, f"flags={flags}")
     assert np.array_equal(acc.view(np.uint32), wacc.view(np.uint32))
+
+
+def test_rgba8_pack_is_a_byte_permutation(abi):
+    """LUMA_FLAG_PACK_RGBA8 with CLAMP_PACK: bytes R,G,B,255 of the same channels as ::RGB's
+    0x00RRGGBB (Renderer.cpp:44-55), sphere-parallel kernel included."""
+    for scene, W, H in [(abi.default_scene(), 96, 54), (abi.synthetic_scene(256), 40, 24)]:
+        kw = dict(spp=2, bounces=5, paths=1, samples=1, mode=1, seed=SEED)
+        ref, _, _ = hip_render(abi, scene, abi.default_camera(W, H), W, H, flags=abi.FLAG_CLAMP_PACK, **kw)
+        got, _, _ = hip_render(abi, scene, abi.default_camera(W, H), W, H,
+                               flags=abi.FLAG_CLAMP_PACK | abi.FLAG_PACK_RGBA8, **kw)
+        b = got.view(np.uint8).reshape(H, W, 4)
+        assert np.array_equal(b[..., 0], (ref >> 16) & 0xFF)
+        assert np.array_equal(b[..., 1], (ref >> 8) & 0xFF)
+        assert np.array_equal(b[..., 2], ref & 0xFF)
+        assert (b[..., 3] == 255).all()
 
 
 def test_posed_camera_render(abi, oracle):

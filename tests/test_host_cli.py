@@ -74,6 +74,23 @@ def test_headless_bmp(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_headless_binary_pnm(tmp_path, oracle):
+    """--output=*.pnm: binary P6 in raster order; the P3 text stays the default."""
+    import numpy as np
+    out = tmp_path / "frame.pnm"
+    r = run("--backend=hip", "--width=33", "--height=17", "--mode=raytrace", "--bounces=1", "--frames=1", "--flags=5",
+            f"--output={out}")
+    assert r.returncode == 0, r.stdout + r.stderr
+    want, _, _ = oracle.render(oracle.default_scene(), oracle.camera(33, 17),
+                               oracle.make_params(33, 17, spp=1, bounces=1, mode=0, flags=5))
+    blob = out.read_bytes()
+    head = b"P6\n33 17\n255\n"
+    assert blob.startswith(head) and len(blob) == len(head) + 33 * 17 * 3
+    rgb = np.frombuffer(blob[len(head):], dtype=np.uint8).reshape(17, 33, 3).astype(np.uint32)
+    assert np.array_equal((rgb[..., 0] << 16) | (rgb[..., 1] << 8) | rgb[..., 2], want)
+
+
+@pytest.mark.gpu
 def test_headless_shared_memory_frame(tmp_path, oracle):
     """--shm publishes every frame in a POSIX shared-memory block, the Linux form of the
     reference's LumaFramebuffer mapping (main.cpp:249-256, :274)."""

@@ -33,6 +33,17 @@ def test_output_ppm_tonemap_pack_kat(oracle, tmp_path):
     assert out.read_bytes() == want
 
 
+def test_pack_variants(oracle):
+    """::RGB (Renderer.cpp:44-55) truncates, shifts and ORs without clamping, so a channel above
+    1.0 bleeds into its neighbour; CLAMP_PACK and PACK_RGBA8 are build-defined variants."""
+    L = oracle.lib()
+    c = np.array([1.1, 0.5, 0.25], dtype=np.float32)          # 280, 127, 63
+    assert L.lo_pack_rgb(f32p(c), 0) == ((280 << 16) | (127 << 8) | 63)
+    assert L.lo_pack_rgb(f32p(c), 4) == ((255 << 16) | (127 << 8) | 63)
+    assert L.lo_pack_rgb(f32p(c), 4 | 16) == (0xFF000000 | (63 << 16) | (127 << 8) | 255)
+    assert L.lo_pack_rgb(f32p(c), 16) == (0xFF000000 | (63 << 16) | (127 << 8) | 280)
+
+
 def test_luma_ppm_layout(oracle, tmp_path):
     """/root/reference/luma.ppm pins export_to_ppm's column-major emission (image.cpp:35-39):
     W text lines of H triples under a 'W H' header."""
