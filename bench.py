@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="profiling aid: render only one band of this many bands on one GPU")
     ap.add_argument("--emulate-rank", type=int, default=0, help="which band --emulate-world renders")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: init the process group and run the gather collectives even with one rank")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks "
                          "(bands are gathered through host memory; not a measurement)")
@@ -122,7 +124,12 @@ def main():
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if a.force_dist:
+        bands.FORCE_COLLECTIVE = True
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+    if use_dist:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -143,7 +150,7 @@ def main():
                              mode=wl["mode"], flags=wl["flags"], seed=SEED)
     stream = torch.cuda.Stream(device=dev)          # a real (non-null) stream: kernels, gather and events share it
     torch.cuda.set_stream(stream)
-    pipelined = world > 1 and (stripe or HEIGHT % world == 0) and not rehearsal
+    pipelined = use_dist and (stripe or HEIGHT % world == 0) and not rehearsal
     pg = bands.PipelinedGather(HEIGHT, WIDTH, rank, world, stripe, dev, rows=y1 - y0) if pipelined or world == 1 else None
     band = pg.bufs[0] if pg else torch.empty((y1 - y0, WIDTH), dtype=torch.int32, device=dev)
     nstep = [0]
@@ -167,7 +174,7 @@ def main():
         if pg:
             pg.finish()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -197,7 +204,7 @@ def main():
     tests_per_launch = st.sphere_tests / (a.steps + 1)
 
     t = torch.tensor([dt, rays_per_launch, tests_per_launch, kernel_ms], dtype=torch.float64, device=red_dev)
-    if world > 1:
+    if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
@@ -236,7 +243,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -15,6 +15,10 @@ def band_rows(height, world_size, rank):
     return rank * height // world_size, (rank + 1) * height // world_size
 
 
+# Rehearsal switch: run the collectives even when world_size == 1 (a one-rank RCCL gather), so
+# the exact torch.distributed calls can be exercised on a one-GPU box.  Off in normal use.
+FORCE_COLLECTIVE = False
+
 STRIPE_ROWS = 15   # 1080, 2160 and 4320 are multiples of 15 * {1, 2, 4, 8}
 
 
@@ -38,7 +42,7 @@ def gather_striped(band, height, width, rank, world_size, stripe, dst=0):
     import torch
     import torch.distributed as dist
 
-    if world_size == 1:
+    if world_size == 1 and not FORCE_COLLECTIVE:
         return band
     gathered = torch.empty((world_size,) + tuple(band.shape), dtype=band.dtype, device=band.device) if rank == dst else None
     dist.gather(band, gather_list=list(gathered.unbind(0)) if rank == dst else None, dst=dst)
@@ -55,7 +59,7 @@ def gather_frame(band, height, width, rank, world_size, dst=0):
     import torch
     import torch.distributed as dist
 
-    if world_size == 1:
+    if world_size == 1 and not FORCE_COLLECTIVE:
         return band
     sizes = [band_rows(height, world_size, r) for r in range(world_size)]
     if len({e - b for b, e in sizes}) == 1:
@@ -93,8 +97,9 @@ class PipelinedGather:
             raise ValueError("pipelined gather needs equal bands")
         rows = height // world_size if rows is None else rows
         self.bufs = [torch.empty((rows, width), dtype=torch.int32, device=device) for _ in range(2)]
+        self.collective = world_size > 1 or FORCE_COLLECTIVE
         self.gathered = ([torch.empty((world_size, rows, width), dtype=torch.int32, device=device) for _ in range(2)]
-                         if rank == dst and world_size > 1 else [None, None])
+                         if rank == dst and self.collective else [None, None])
         self.works = [None, None]
         self.last = None
 
@@ -109,7 +114,7 @@ class PipelinedGather:
         import torch.distributed as dist
         b = i & 1
         self.last = b
-        if self.world == 1:
+        if not self.collective:
             return
         g = self.gathered[b]
         self.works[b] = dist.gather(self.bufs[b], gather_list=list(g.unbind(0)) if g is not None else None,
@@ -122,7 +127,7 @@ class PipelinedGather:
                 self.works[b] = None
         if self.last is None:
             return None
-        if self.world == 1:
+        if not self.collective:
             return self.bufs[self.last]
         if self.rank != self.dst:
             return None
