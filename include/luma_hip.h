@@ -141,6 +141,43 @@ int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* t
 /* Device pointer of the context's own band framebuffer (valid until set_frame/destroy). */
 int luma_hip_target_device(luma_ctx* ctx, uint32_t** target_dev);
 
+/* luma_hip_render for a context that holds one band of a frame assembled in HOST memory:
+ * frame_host is the whole width*height frame (Renderer::render_to's `target`, Renderer.cpp:461)
+ * and the call writes only this context's rows into it, at their place in the frame (one copy for
+ * a contiguous band, one strided copy for interleaved stripes).  Contexts of different devices may
+ * be driven from different host threads into the same frame_host. */
+int luma_hip_render_frame(luma_ctx* ctx, const luma_params* params, uint32_t* frame_host,
+                          luma_stats* stats);
+
+/* ---- several devices in one process (`--gpus N`, SURVEY.md 8b "internally N devices") ---- */
+
+/* A group is n contexts, one per entry of device_ids (NULL: devices 0..n-1), that render one
+ * frame together: the frame is cut into interleaved 15-row stripes when height divides by
+ * 15*n, else into contiguous scanline bands; every device renders its part on its own stream at
+ * the same time and copies it straight into the caller's host frame over its own PCIe link (the
+ * reference's target is host memory, so no device-to-device gather is needed; the
+ * one-process-per-GPU path with a RCCL gather is bench.py's).  The frame is bit-identical to a
+ * one-device render.  A device id may repeat (several bands on one GPU; used by the tests).
+ * No counterpart in the reference, which is single-threaded CPU code. */
+typedef struct luma_group luma_group;
+int  luma_hip_device_count(int* count);
+int  luma_hip_group_create(luma_group** out, int n, const int* device_ids);
+void luma_hip_group_destroy(luma_group* g);
+int  luma_hip_group_size(luma_group* g, int* n);
+int  luma_hip_group_context(luma_group* g, int i, luma_ctx** ctx);   /* borrowed: read-back hooks, stats */
+int  luma_hip_group_set_scene(luma_group* g, const luma_sphere* spheres, uint32_t n);
+int  luma_hip_group_set_camera(luma_group* g, const luma_camera* cam);
+int  luma_hip_group_set_frame(luma_group* g, uint32_t width, uint32_t height);
+int  luma_hip_group_reset(luma_group* g);
+/* Renderer::render_to over the whole frame: frame_host receives width*height pixels.  kernel_ms is
+ * the slowest device's, rays / sphere_tests are summed.  After a failure call luma_hip_group_reset
+ * (devices may have advanced unevenly). */
+int  luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* frame_host,
+                           luma_stats* stats);
+/* Renderer::accumulated_data of the whole frame (width*height*3 floats, AoS rgb, renderer.h:56),
+ * put together from the members' bands. */
+int  luma_hip_group_read_accum(luma_group* g, float* rgb_host);
+
 /* ---- read-back hooks ----------------------------------------------------------- */
 
 /* Renderer::accumulated_data for the band as the reference lays it out: W*rows*3 floats,

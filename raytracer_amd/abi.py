@@ -23,6 +23,9 @@ SYMBOLS = [
     "luma_hip_generate_rays", "luma_camera_default", "luma_camera_from_pose",
     "luma_scene_default", "luma_scene_synthetic", "luma_hip_strerror", "luma_hip_last_error",
     "luma_hip_abi_version",
+    "luma_hip_render_frame", "luma_hip_device_count", "luma_hip_group_create", "luma_hip_group_destroy",
+    "luma_hip_group_size", "luma_hip_group_context", "luma_hip_group_set_scene", "luma_hip_group_set_camera",
+    "luma_hip_group_set_frame", "luma_hip_group_reset", "luma_hip_group_render", "luma_hip_group_read_accum",
 ]
 
 
@@ -88,6 +91,18 @@ def lib():
                                             C.c_float, C.c_float, C.POINTER(Camera)]),
         "luma_scene_default": (C.c_int, [C.POINTER(Sphere)]),
         "luma_scene_synthetic": (C.c_int, [C.POINTER(Sphere), C.c_uint32, C.c_uint64]),
+        "luma_hip_render_frame": (C.c_int, [ctx, C.POINTER(Params), u32p, C.POINTER(Stats)]),
+        "luma_hip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+        "luma_hip_group_create": (C.c_int, [ctxp, C.c_int, C.POINTER(C.c_int)]),
+        "luma_hip_group_destroy": (None, [ctx]),
+        "luma_hip_group_size": (C.c_int, [ctx, C.POINTER(C.c_int)]),
+        "luma_hip_group_context": (C.c_int, [ctx, C.c_int, ctxp]),
+        "luma_hip_group_set_scene": (C.c_int, [ctx, C.POINTER(Sphere), C.c_uint32]),
+        "luma_hip_group_set_camera": (C.c_int, [ctx, C.POINTER(Camera)]),
+        "luma_hip_group_set_frame": (C.c_int, [ctx, C.c_uint32, C.c_uint32]),
+        "luma_hip_group_reset": (C.c_int, [ctx]),
+        "luma_hip_group_render": (C.c_int, [ctx, C.POINTER(Params), u32p, C.POINTER(Stats)]),
+        "luma_hip_group_read_accum": (C.c_int, [ctx, f32p]),
         "luma_hip_strerror": (C.c_char_p, [C.c_int]),
         "luma_hip_last_error": (C.c_char_p, []),
         "luma_hip_abi_version": (C.c_int, []),
@@ -144,18 +159,26 @@ def make_params(width, height, spp=1, bounces=1, paths=1, samples=1, mode=MODE_R
     return Params(width, height, samples, bounces, paths, mode, spp, flags, seed)
 
 
+def device_count():
+    n = C.c_int()
+    check(lib().luma_hip_device_count(C.byref(n)), "luma_hip_device_count")
+    return n.value
+
+
 class Context:
     """Owns one luma_ctx (one device, one scanline band)."""
 
-    def __init__(self, device_id=-1):
-        self._h = C.c_void_p()
-        check(lib().luma_hip_create(C.byref(self._h), device_id), "luma_hip_create")
+    def __init__(self, device_id=-1, _borrowed=None):
+        self._owned = _borrowed is None
+        self._h = C.c_void_p() if self._owned else _borrowed
+        if self._owned:
+            check(lib().luma_hip_create(C.byref(self._h), device_id), "luma_hip_create")
         self.width = self.height = self.row_begin = self.row_end = 0
 
     def close(self):
-        if self._h:
+        if self._h and self._owned:
             lib().luma_hip_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __enter__(self):
         return self
@@ -168,6 +191,13 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def render_frame(self, params, frame, want_stats=False):
+        """luma_hip_render_frame: writes this context's rows into `frame` ([H, W] uint32, in place)."""
+        st = Stats()
+        check(lib().luma_hip_render_frame(self._h, C.byref(params), _u32p(frame), C.byref(st) if want_stats else None),
+              "luma_hip_render_frame")
+        return st
 
     def set_scene(self, spheres):
         n = len(spheres)
@@ -228,3 +258,63 @@ class Context:
         out = np.empty((self.rows, self.width, 3), dtype=np.float32)
         check(lib().luma_hip_generate_rays(self._h, _f32p(out)), "luma_hip_generate_rays")
         return out
+
+
+class Group:
+    """Owns one luma_group: n contexts (one per device id) that render one host frame together."""
+
+    def __init__(self, device_ids):
+        ids = (C.c_int * len(device_ids))(*device_ids)
+        self._h = C.c_void_p()
+        check(lib().luma_hip_group_create(C.byref(self._h), len(device_ids), ids), "luma_hip_group_create")
+        self.width = self.height = 0
+
+    def close(self):
+        if self._h:
+            lib().luma_hip_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __len__(self):
+        n = C.c_int()
+        check(lib().luma_hip_group_size(self._h, C.byref(n)), "luma_hip_group_size")
+        return n.value
+
+    def context(self, i, rows):
+        """Borrowed Context of member i; `rows` = its row count (for the read-back shapes)."""
+        h = C.c_void_p()
+        check(lib().luma_hip_group_context(self._h, i, C.byref(h)), "luma_hip_group_context")
+        c = Context(_borrowed=h)
+        c.width, c.height, c.row_begin, c.row_end = self.width, self.height, 0, rows
+        return c
+
+    def set_scene(self, spheres):
+        n = len(spheres)
+        check(lib().luma_hip_group_set_scene(self._h, spheres if n else None, n), "luma_hip_group_set_scene")
+
+    def set_camera(self, cam):
+        check(lib().luma_hip_group_set_camera(self._h, C.byref(cam)), "luma_hip_group_set_camera")
+
+    def set_frame(self, width, height):
+        check(lib().luma_hip_group_set_frame(self._h, width, height), "luma_hip_group_set_frame")
+        self.width, self.height = width, height
+
+    def reset(self):
+        check(lib().luma_hip_group_reset(self._h), "luma_hip_group_reset")
+
+    def read_accum(self):
+        out = np.empty((self.height, self.width, 3), dtype=np.float32)
+        check(lib().luma_hip_group_read_accum(self._h, _f32p(out)), "luma_hip_group_read_accum")
+        return out
+
+    def render(self, params, want_stats=True):
+        out = np.empty((self.height, self.width), dtype=np.uint32)
+        st = Stats()
+        check(lib().luma_hip_group_render(self._h, C.byref(params), _u32p(out), C.byref(st) if want_stats else None),
+              "luma_hip_group_render")
+        return out, st

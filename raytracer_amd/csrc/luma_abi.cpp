@@ -236,7 +236,27 @@ int collect_stats(luma_ctx* ctx, hipStream_t stream, luma_stats* stats)
     return LUMA_OK;
 }
 
+// Copies the band in ctx->d_target to its rows of a full host frame: contiguous bands in one
+// copy, interleaved stripes as one strided copy (chunk q of `stripe` rows lands `pitch` rows apart).
+int copy_band_to_frame(const luma_ctx* ctx, uint32_t* frame_host)
+{
+    const size_t row_bytes = static_cast<size_t>(ctx->width) * sizeof(uint32_t);
+    uint32_t* dst = frame_host + static_cast<size_t>(ctx->row_begin) * ctx->width;
+    if (ctx->stripe == ctx->rows) {
+        LUMA_HIP_TRY(hipMemcpy(dst, ctx->d_target, ctx->rows * row_bytes, hipMemcpyDeviceToHost));
+    } else {
+        LUMA_HIP_TRY(hipMemcpy2D(dst, ctx->pitch * row_bytes, ctx->d_target, ctx->stripe * row_bytes,
+                                 ctx->stripe * row_bytes, ctx->rows / ctx->stripe, hipMemcpyDeviceToHost));
+    }
+    return LUMA_OK;
+}
+
 }  // namespace
+
+struct luma_group {
+    std::vector<luma_ctx*> ctx;
+    bool have_frame = false;
+};
 
 extern "C" {
 
@@ -471,6 +491,183 @@ int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* t
         std::memset(stats, 0, sizeof *stats);
         if (int rc = collect_stats(ctx, s, stats)) { return rc; }
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return LUMA_OK;
+}
+
+int luma_hip_render_frame(luma_ctx* ctx, const luma_params* params, uint32_t* frame_host, luma_stats* stats)
+{
+    if (int rc = check_params(ctx, params)) { return rc; }
+    if (!frame_host) { return fail(LUMA_E_ARG, "luma_hip_render_frame", "null frame"); }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_render_frame", "hipSetDevice failed"); }
+
+    const auto t0 = std::chrono::steady_clock::now();
+    if (int rc = enqueue_render(ctx, params, ctx->d_target, ctx->stream)) { return rc; }
+    LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+    if (int rc = copy_band_to_frame(ctx, frame_host)) { return rc; }
+    const auto t2 = std::chrono::steady_clock::now();
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        if (int rc = collect_stats(ctx, ctx->stream, stats)) { return rc; }
+        stats->gather_ms = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        stats->total_ms = std::chrono::duration<double, std::milli>(t2 - t0).count();
+    }
+    return LUMA_OK;
+}
+
+int luma_hip_device_count(int* count)
+{
+    if (!count) { return fail(LUMA_E_ARG, "luma_hip_device_count", "null argument"); }
+    *count = 0;
+    LUMA_HIP_TRY(hipGetDeviceCount(count));
+    return LUMA_OK;
+}
+
+int luma_hip_group_create(luma_group** out, int n, const int* device_ids)
+{
+    if (!out) { return fail(LUMA_E_ARG, "luma_hip_group_create", "null out pointer"); }
+    *out = nullptr;
+    if (n < 1 || n > 64) { return fail(LUMA_E_ARG, "luma_hip_group_create", "need 1 <= n <= 64 devices"); }
+    luma_group* g = new (std::nothrow) luma_group();
+    if (!g) { return fail(LUMA_E_NOMEM, "luma_hip_group_create", "host allocation failed"); }
+    try { g->ctx.reserve(static_cast<size_t>(n)); } catch (...) {
+        delete g;
+        return fail(LUMA_E_NOMEM, "luma_hip_group_create", "host allocation failed");
+    }
+    for (int i = 0; i < n; i++) {
+        luma_ctx* c = nullptr;
+        const int dev = device_ids ? device_ids[i] : i;
+        if (dev < 0) { luma_hip_group_destroy(g); return fail(LUMA_E_ARG, "luma_hip_group_create", "negative device id"); }
+        if (int rc = luma_hip_create(&c, dev)) { luma_hip_group_destroy(g); return rc; }   // message already set
+        g->ctx.push_back(c);
+    }
+    *out = g;
+    return LUMA_OK;
+}
+
+void luma_hip_group_destroy(luma_group* g)
+{
+    if (!g) { return; }
+    for (luma_ctx* c : g->ctx) { luma_hip_destroy(c); }
+    delete g;
+}
+
+int luma_hip_group_size(luma_group* g, int* n)
+{
+    if (!g || !n) { return fail(LUMA_E_ARG, "luma_hip_group_size", "null argument"); }
+    *n = static_cast<int>(g->ctx.size());
+    return LUMA_OK;
+}
+
+int luma_hip_group_context(luma_group* g, int i, luma_ctx** ctx)
+{
+    if (!g || !ctx) { return fail(LUMA_E_ARG, "luma_hip_group_context", "null argument"); }
+    if (i < 0 || static_cast<size_t>(i) >= g->ctx.size()) { return fail(LUMA_E_ARG, "luma_hip_group_context", "index out of range"); }
+    *ctx = g->ctx[static_cast<size_t>(i)];
+    return LUMA_OK;
+}
+
+int luma_hip_group_set_scene(luma_group* g, const luma_sphere* spheres, uint32_t n)
+{
+    if (!g) { return fail(LUMA_E_ARG, "luma_hip_group_set_scene", "null group"); }
+    for (luma_ctx* c : g->ctx) { if (int rc = luma_hip_set_scene(c, spheres, n)) { return rc; } }
+    return LUMA_OK;
+}
+
+int luma_hip_group_set_camera(luma_group* g, const luma_camera* cam)
+{
+    if (!g) { return fail(LUMA_E_ARG, "luma_hip_group_set_camera", "null group"); }
+    for (luma_ctx* c : g->ctx) { if (int rc = luma_hip_set_camera(c, cam)) { return rc; } }
+    return LUMA_OK;
+}
+
+int luma_hip_group_set_frame(luma_group* g, uint32_t width, uint32_t height)
+{
+    const char* who = "luma_hip_group_set_frame";
+    if (!g) { return fail(LUMA_E_ARG, who, "null group"); }
+    const uint32_t n = static_cast<uint32_t>(g->ctx.size());
+    if (height < n) { return fail(LUMA_E_ARG, who, "fewer rows than devices: a band would be empty"); }
+    g->have_frame = false;
+    constexpr uint32_t kStripeRows = 15;   // 1080, 2160 and 4320 are multiples of 15 * {1, 2, 4, 8}
+    const bool striped = n > 1 && height % (kStripeRows * n) == 0;
+    for (uint32_t i = 0; i < n; i++) {
+        int rc;
+        if (striped) {
+            rc = luma_hip_set_frame_striped(g->ctx[i], width, height, kStripeRows, i, n);
+        } else {
+            const uint32_t y0 = static_cast<uint32_t>(static_cast<uint64_t>(i) * height / n);
+            const uint32_t y1 = static_cast<uint32_t>(static_cast<uint64_t>(i + 1) * height / n);
+            rc = luma_hip_set_frame(g->ctx[i], width, height, y0, y1);
+        }
+        if (rc) { return rc; }
+    }
+    g->have_frame = true;
+    return LUMA_OK;
+}
+
+int luma_hip_group_reset(luma_group* g)
+{
+    if (!g) { return fail(LUMA_E_ARG, "luma_hip_group_reset", "null group"); }
+    for (luma_ctx* c : g->ctx) { if (int rc = luma_hip_reset(c)) { return rc; } }
+    return LUMA_OK;
+}
+
+int luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* frame_host, luma_stats* stats)
+{
+    const char* who = "luma_hip_group_render";
+    if (!g) { return fail(LUMA_E_ARG, who, "null group"); }
+    if (!frame_host) { return fail(LUMA_E_ARG, who, "null frame"); }
+    if (!g->have_frame) { return fail(LUMA_E_STATE, who, "luma_hip_group_set_frame not called"); }
+    for (luma_ctx* c : g->ctx) { if (int rc = check_params(c, params)) { return rc; } }   // nothing launched yet
+
+    const auto t0 = std::chrono::steady_clock::now();
+    for (luma_ctx* c : g->ctx) {                                   // every device starts its band ...
+        DeviceScope scope(c->device);
+        if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+        if (int rc = enqueue_render(c, params, c->d_target, c->stream)) { return rc; }
+    }
+    double copy_ms = 0.0;
+    for (luma_ctx* c : g->ctx) {                                   // ... and hands it over as it finishes
+        DeviceScope scope(c->device);
+        if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+        LUMA_HIP_TRY(hipStreamSynchronize(c->stream));
+        const auto c0 = std::chrono::steady_clock::now();
+        if (int rc = copy_band_to_frame(c, frame_host)) { return rc; }
+        copy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        for (luma_ctx* c : g->ctx) {
+            DeviceScope scope(c->device);
+            if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+            luma_stats one{};
+            if (int rc = collect_stats(c, c->stream, &one)) { return rc; }
+            stats->kernel_ms = one.kernel_ms > stats->kernel_ms ? one.kernel_ms : stats->kernel_ms;
+            stats->rays += one.rays;
+            stats->sphere_tests += one.sphere_tests;
+        }
+        stats->gather_ms = copy_ms;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return LUMA_OK;
+}
+
+int luma_hip_group_read_accum(luma_group* g, float* rgb_host)
+{
+    const char* who = "luma_hip_group_read_accum";
+    if (!g || !rgb_host) { return fail(LUMA_E_ARG, who, "null argument"); }
+    if (!g->have_frame) { return fail(LUMA_E_STATE, who, "luma_hip_group_set_frame not called"); }
+    std::vector<float> band;
+    for (luma_ctx* c : g->ctx) {
+        try { band.resize(3 * c->band_pixels()); } catch (...) { return fail(LUMA_E_NOMEM, who, "host allocation failed"); }
+        if (int rc = luma_hip_read_accum(c, band.data())) { return rc; }
+        const size_t row_floats = 3 * static_cast<size_t>(c->width);
+        for (uint32_t yl = 0; yl < c->rows; yl++) {             // same mapping as global_row() in the kernels
+            const size_t y = c->row_begin + static_cast<size_t>(yl / c->stripe) * c->pitch + (yl % c->stripe);
+            std::memcpy(rgb_host + y * row_floats, band.data() + yl * row_floats, row_floats * sizeof(float));
+        }
     }
     return LUMA_OK;
 }

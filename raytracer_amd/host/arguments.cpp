@@ -1,5 +1,7 @@
 #include "arguments.h"
 
+#include <algorithm>
+
 #include <charconv>
 #include <functional>
 #include <unordered_map>
@@ -63,6 +65,19 @@ void Arguments::parse(const std::vector<std::string>& arguments)
             std::uint32_t n = 0;
             if (!whole_number(v, n) || n < 1 || n > 8) { return false; }
             _options.gpus = n; return true; } } },
+        { "devices", { "device list", [](const std::string& v) {   // e.g. --devices=0,1,2,3 (overrides --gpus)
+            std::vector<int> ids;
+            std::size_t at = 0;
+            while (at <= v.size()) {
+                const std::size_t comma = std::min(v.find(',', at), v.size());
+                std::uint32_t id = 0;
+                if (!whole_number(v.substr(at, comma - at), id) || id > 1023) { return false; }
+                ids.push_back(static_cast<int>(id));
+                at = comma + 1;
+            }
+            if (ids.empty() || ids.size() > 64) { return false; }
+            _options.devices = ids;
+            _options.gpus = static_cast<std::uint32_t>(ids.size()); return true; } } },
         { "seed",    { "seed", [](const std::string& v) {
             std::uint64_t s = 0;
             const bool hex = v.size() > 2 && v[0] == '0' && (v[1] == 'x' || v[1] == 'X');

@@ -1,5 +1,5 @@
 // arguments.h -- luma::Options / luma::Arguments as in the reference (arguments.h:9-49), plus
-// the flags this backend adds: --backend, --gpus, --seed, --frames, --output, --flags.
+// the flags this backend adds: --backend, --gpus, --devices, --seed, --frames, --output, --flags, --shm.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -20,7 +20,8 @@ struct Options {
     Context context = Context::INTERACTIVE;
     // additions
     Backend backend = Backend::CPU;
-    std::uint32_t gpus = 1;
+    std::uint32_t gpus = 1;         // devices that share one frame (one process, luma_hip_group_*)
+    std::vector<int> devices;       // explicit device ids for them (default 0..gpus-1; an id may repeat)
     std::uint64_t seed = 0x4C554D41ull;
     std::uint32_t frames = 1;       // headless: frames to accumulate before writing the image
     std::uint32_t flags = 0;        // LUMA_FLAG_* (0 == reference behaviour)

@@ -3,7 +3,7 @@
 // "[DELIVERED FRAME]:n:ms" per frame, then write the frame with Image::export_to_ppm
 // (the reference's Ctrl+P path, main.cpp:95-102).  Display (olc, D3D11) is not built.
 //
-//   luma_headless --backend hip --width=1920 --height=1080 --mode=pathtrace --bounces=5
+//   luma_headless --backend hip --gpus 8 --width=1920 --height=1080 --mode=pathtrace --bounces=5
 //                 --samples=1 --paths=1 --frames=64 --output=frame.ppm
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -65,15 +65,13 @@ int main(int argc, char** argv)
         luma::log("only --context=headless is built on Linux (the interactive and directx contexts need a window)");
         return 2;
     }
-    if (luma::_options.gpus != 1) {
-        luma::log("--gpus=N runs one process per GPU: launch bench.py with torch.distributed.run (INTEGRATION.md section 3)");
-        return 2;
-    }
     if (luma::_options.width == 0 || luma::_options.height == 0) {
         luma::log("--width and --height must be positive");
         return 2;
     }
 
+    luma::log(std::to_string(luma::_options.width) + "x" + std::to_string(luma::_options.height) + " on "
+              + std::to_string(luma::_options.gpus) + " device(s)");
     luma::Renderer renderer{};
     const std::size_t pixels = static_cast<std::size_t>(luma::_options.width) * luma::_options.height;
     std::unique_ptr<std::uint32_t[]> framebuffer(new std::uint32_t[pixels]());

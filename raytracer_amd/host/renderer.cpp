@@ -2,6 +2,7 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <string>
 
 #include "arguments.h"
 #include "log.h"
@@ -28,11 +29,23 @@ Renderer::Renderer() noexcept
         log("this build has only the HIP backend (--backend=hip); the CPU loop is the reference's own Renderer.cpp");
         std::abort();
     }
-    if (luma_hip_create(&ctx_, -1) != LUMA_OK) { die("luma_hip_create"); }
-    if (luma_hip_set_frame(ctx_, _options.width, _options.height, 0, _options.height) != LUMA_OK) { die("luma_hip_set_frame"); }
+    // --gpus=N: N devices of this process share the frame (stripes or bands, luma_hip.h);
+    // --devices=a,b,... names them.  The default is the current device alone.
+    std::vector<int> ids = _options.devices;
+    if (ids.empty()) {
+        int count = 0;
+        if (luma_hip_device_count(&count) != LUMA_OK) { die("luma_hip_device_count"); }
+        if (_options.gpus > static_cast<std::uint32_t>(count)) {
+            log("--gpus=" + std::to_string(_options.gpus) + " but only " + std::to_string(count) + " HIP device(s) are visible");
+            std::abort();
+        }
+        for (std::uint32_t i = 0; i < _options.gpus; i++) { ids.push_back(static_cast<int>(i)); }
+    }
+    if (luma_hip_group_create(&group_, static_cast<int>(ids.size()), ids.data()) != LUMA_OK) { die("luma_hip_group_create"); }
+    if (luma_hip_group_set_frame(group_, _options.width, _options.height) != LUMA_OK) { die("luma_hip_group_set_frame"); }
 }
 
-Renderer::~Renderer() { luma_hip_destroy(ctx_); }
+Renderer::~Renderer() { luma_hip_group_destroy(group_); }
 
 void Renderer::render_to(std::uint32_t* target, olc::PixelGameEngine* pge) noexcept
 {
@@ -41,15 +54,15 @@ void Renderer::render_to(std::uint32_t* target, olc::PixelGameEngine* pge) noexc
 
     camera.update(frametime, pge);                                   // :375
     if (scene_dirty_) {
-        if (luma_hip_set_scene(ctx_, reinterpret_cast<const luma_sphere*>(spheres.data()),
-                               static_cast<std::uint32_t>(spheres.size())) != LUMA_OK) { die("luma_hip_set_scene"); }
+        if (luma_hip_group_set_scene(group_, reinterpret_cast<const luma_sphere*>(spheres.data()),
+                                     static_cast<std::uint32_t>(spheres.size())) != LUMA_OK) { die("luma_hip_group_set_scene"); }
         scene_dirty_ = false;
     }
     const luma_camera cam = camera.abi();
-    if (luma_hip_set_camera(ctx_, &cam) != LUMA_OK) { die("luma_hip_set_camera"); }
+    if (luma_hip_group_set_camera(group_, &cam) != LUMA_OK) { die("luma_hip_group_set_camera"); }
     if (camera.moved) {                                              // :377-390
         frame_count = 1.f;
-        if (luma_hip_reset(ctx_) != LUMA_OK) { die("luma_hip_reset"); }
+        if (luma_hip_group_reset(group_) != LUMA_OK) { die("luma_hip_group_reset"); }
         camera.moved = false;
     }
 
@@ -63,7 +76,7 @@ void Renderer::render_to(std::uint32_t* target, olc::PixelGameEngine* pge) noexc
     p.spp = 1;                                                       // one render_to == one frame
     p.flags = _options.flags;
     p.seed = _options.seed;
-    if (luma_hip_render(ctx_, &p, target, &stats_) != LUMA_OK) { die("luma_hip_render"); }   // :392-467
+    if (luma_hip_group_render(group_, &p, target, &stats_) != LUMA_OK) { die("luma_hip_group_render"); }   // :392-467
 
     frametime = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - begin).count();   // :469
     frame_count += 1.f;                                              // :470
@@ -72,7 +85,7 @@ void Renderer::render_to(std::uint32_t* target, olc::PixelGameEngine* pge) noexc
 bool Renderer::sync_accumulated_data()
 {
     accumulated_data.resize(static_cast<std::size_t>(_options.width) * _options.height);
-    return luma_hip_read_accum(ctx_, accumulated_data.data()->data()) == LUMA_OK;
+    return luma_hip_group_read_accum(group_, accumulated_data.data()->data()) == LUMA_OK;
 }
 
 }  // namespace luma

@@ -38,10 +38,10 @@ public:
     // Copies the device-resident accumulation buffer into accumulated_data (renderer.h:56).
     bool sync_accumulated_data();
     const luma_stats& last_stats() const noexcept { return stats_; }
-    luma_ctx* context() const noexcept { return ctx_; }
+    luma_group* group() const noexcept { return group_; }
 
 private:
-    luma_ctx* ctx_ = nullptr;
+    luma_group* group_ = nullptr;           // _options.gpus devices sharing the frame (one is the usual case)
     bool scene_dirty_ = true;
     luma_stats stats_{};
 };

@@ -375,6 +375,85 @@ def test_interleaved_stripes_equal_full_frame(abi, oracle, W, H, stripe, n, scen
         assert e.value.code == abi.E_ARG
 
 
+@pytest.mark.parametrize("W,H,ids,scene_n", [
+    (96, 60, [0, 0], 0),          # 60 % (15*2) == 0: interleaved stripes
+    (96, 60, [0, 0, 0], 0),       # 60 % 45 != 0: contiguous bands of 20 rows
+    (70, 53, [0, 0, 0, 0], 0),    # ragged bands 13,13,13,14
+    (48, 120, [0] * 8, 300),      # eight stripes-of-15 bands, sphere-parallel kernel
+    (64, 36, [0], 0),             # a group of one
+])
+def test_group_renders_whole_frame(abi, oracle, W, H, ids, scene_n):
+    """luma_hip_group_*: n contexts in one process render one host frame together (here all on
+    device 0); frame, accumulators and ray count equal the one-context render and the oracle,
+    call after call (progressive accumulation)."""
+    kw = dict(spp=2, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    scene = abi.synthetic_scene(scene_n) if scene_n else abi.default_scene()
+    oscene = oracle.synthetic_scene(scene_n) if scene_n else oracle.default_scene()
+    params = abi.make_params(W, H, **kw)
+    r = oracle.Renderer(oscene, oracle.camera(W, H), W, H)
+    with abi.Group(ids) as g:
+        assert len(g) == len(ids)
+        g.set_scene(scene)
+        g.set_camera(abi.default_camera(W, H))
+        g.set_frame(W, H)
+        rays = 0
+        for call in range(2):
+            got, st = g.render(params)
+            ost = r.render(oracle.make_params(W, H, **kw))
+            assert_frames_equal(got, r.target, f"group of {len(ids)}, call {call}")
+            assert np.array_equal(g.read_accum().view(np.uint32), r.accum.view(np.uint32))
+            rays += st.rays
+            assert st.kernel_ms > 0 and st.sphere_tests == st.rays * len(scene)
+        g.reset()
+        again, _ = g.render(params)
+    first = oracle.Renderer(oscene, oracle.camera(W, H), W, H)
+    first.render(oracle.make_params(W, H, **kw))
+    assert_frames_equal(again, first.target, "after group reset")
+
+
+def test_render_frame_scatters_bands_into_one_frame(abi):
+    """luma_hip_render_frame: each context writes only its own rows of the shared host frame."""
+    W, H, n = 80, 90, 3
+    kw = dict(spp=2, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    want, _, _ = hip_render(abi, abi.default_scene(), abi.default_camera(W, H), W, H, **kw)
+    for striped in (True, False):
+        frame = np.full((H, W), 0xDEADBEEF, dtype=np.uint32)
+        for rnk in range(n):
+            with abi.Context(0) as ctx:
+                ctx.set_scene(abi.default_scene())
+                ctx.set_camera(abi.default_camera(W, H))
+                if striped:
+                    ctx.set_frame_striped(W, H, 15, rnk, n)
+                else:
+                    ctx.set_frame(W, H, rnk * H // n, (rnk + 1) * H // n)
+                before = frame.copy()
+                ctx.render_frame(abi.make_params(W, H, **kw), frame)
+                touched = (frame != before).any(axis=1).sum()
+                assert touched <= H // n
+        assert_frames_equal(frame, want, f"render_frame striped={striped}")
+
+
+def test_group_errors(abi):
+    with pytest.raises(abi.LumaError) as e:
+        abi.Group([])
+    assert e.value.code == abi.E_ARG
+    with pytest.raises(abi.LumaError) as e:
+        abi.Group([abi.device_count()])          # one past the last device
+    assert e.value.code == abi.E_ARG
+    with abi.Group([0, 0, 0]) as g:
+        g.set_scene(abi.default_scene())
+        g.set_camera(abi.default_camera(16, 2))
+        with pytest.raises(abi.LumaError) as e:
+            g.render(abi.make_params(16, 2))
+        assert e.value.code == abi.E_STATE
+        with pytest.raises(abi.LumaError) as e:
+            g.set_frame(16, 2)                   # fewer rows than devices
+        assert e.value.code == abi.E_ARG
+        g.set_frame(16, 3)
+        img, _ = g.render(abi.make_params(16, 3))
+        assert img.shape == (3, 16)
+
+
 # ---- device-resident target (what bench.py times) ------------------------------------
 
 def test_render_device_matches_host_target(abi):

@@ -31,8 +31,13 @@ def test_parser_logs_and_continues():
 
 
 def test_parser_space_and_equals_forms():
-    r = run("--backend", "hip", "--gpus", "4", "--width=64", "--height", "36")
-    assert r.returncode == 2 and "one process per GPU" in r.stdout      # --gpus 4 parsed from the space form
+    # without a GPU the run ends at the first HIP call, after the options were echoed
+    r = run("--backend", "hip", "--gpus", "4", "--width=64", "--height", "36", "--context=directx")
+    assert r.returncode == 2
+    r = run("--devices=0,0,1", "--width=0")
+    assert r.returncode == 2 and "unrecognized" not in r.stdout
+    r = run("--devices=0,,1", "--context=directx")
+    assert "unrecognized device list `0,,1`" in r.stdout
     r = run("--gpus=9", "--context=directx")
     assert "unrecognized gpu count `9`" in r.stdout
     r = run("--width=0", "--height=10")
@@ -58,6 +63,32 @@ def test_headless_ppm_matches_oracle(tmp_path, oracle, args, okw):
     ref = tmp_path / "oracle.ppm"
     assert oracle.export_ppm(want, str(ref)) == 0
     assert out.read_bytes() == ref.read_bytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sel,H", [("--devices=0,0", 60), ("--devices=0,0,0", 50), ("--gpus=1", 36)])
+def test_headless_several_devices_one_frame(tmp_path, oracle, sel, H):
+    """--gpus N / --devices: the devices of one process share the frame (luma_hip_group_*); here the
+    same GPU stands in for all of them.  The PPM equals the oracle's byte for byte."""
+    W = 96
+    out = tmp_path / "frame.ppm"
+    r = run("--backend", "hip", sel, f"--width={W}", f"--height={H}", "--mode=pathtrace", "--bounces=5", "--samples=1",
+            "--paths=1", "--frames=4", f"--output={out}")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"on {sel.count(',') + 1} device(s)" in r.stdout
+    want, _, _ = oracle.render(oracle.default_scene(), oracle.camera(W, H),
+                               oracle.make_params(W, H, seed=0x4C554D41, spp=4, bounces=5, mode=1, flags=0))
+    ref = tmp_path / "oracle.ppm"
+    assert oracle.export_ppm(want, str(ref)) == 0
+    assert out.read_bytes() == ref.read_bytes()
+
+
+@pytest.mark.gpu
+def test_headless_too_many_gpus_is_refused():
+    r = run("--backend", "hip", "--gpus=8", "--width=32", "--height=32")
+    if "on 8 device(s)" in r.stdout and r.returncode == 0:
+        pytest.skip("this box really has 8 GPUs")
+    assert r.returncode != 0 and "HIP device(s) are visible" in r.stdout
 
 
 @pytest.mark.gpu
