@@ -15,6 +15,7 @@
 #ifndef LUMA_HIP_H
 #define LUMA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -177,6 +178,15 @@ int  luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* f
 /* Renderer::accumulated_data of the whole frame (width*height*3 floats, AoS rgb, renderer.h:56),
  * put together from the members' bands. */
 int  luma_hip_group_read_accum(luma_group* g, float* rgb_host);
+
+/* ---- host frames ---------------------------------------------------------------- */
+
+/* Page-locked host memory for a frame that luma_hip_render / _render_frame / _group_render fill
+ * (stands in for `new std::uint32_t[width * height]`, main.cpp:63,:259): the device then writes
+ * it by DMA at PCIe rate instead of through the runtime's staging buffers.  Any host pointer is
+ * accepted by the render calls; this one is only faster.  Visible to every device. */
+int  luma_hip_host_alloc(void** out, size_t bytes);
+void luma_hip_host_free(void* p);
 
 /* ---- read-back hooks ----------------------------------------------------------- */
 

@@ -26,6 +26,7 @@ SYMBOLS = [
     "luma_hip_render_frame", "luma_hip_device_count", "luma_hip_group_create", "luma_hip_group_destroy",
     "luma_hip_group_size", "luma_hip_group_context", "luma_hip_group_set_scene", "luma_hip_group_set_camera",
     "luma_hip_group_set_frame", "luma_hip_group_reset", "luma_hip_group_render", "luma_hip_group_read_accum",
+    "luma_hip_host_alloc", "luma_hip_host_free",
 ]
 
 
@@ -103,6 +104,8 @@ def lib():
         "luma_hip_group_reset": (C.c_int, [ctx]),
         "luma_hip_group_render": (C.c_int, [ctx, C.POINTER(Params), u32p, C.POINTER(Stats)]),
         "luma_hip_group_read_accum": (C.c_int, [ctx, f32p]),
+        "luma_hip_host_alloc": (C.c_int, [ctxp, C.c_size_t]),
+        "luma_hip_host_free": (None, [C.c_void_p]),
         "luma_hip_strerror": (C.c_char_p, [C.c_int]),
         "luma_hip_last_error": (C.c_char_p, []),
         "luma_hip_abi_version": (C.c_int, []),
@@ -157,6 +160,28 @@ def camera_from_pose(width, height, pos, pitch, yaw, fov=70.0, near=0.1, far=100
 def make_params(width, height, spp=1, bounces=1, paths=1, samples=1, mode=MODE_RAYTRACE, flags=0,
                 seed=0x4C554D41):
     return Params(width, height, samples, bounces, paths, mode, spp, flags, seed)
+
+
+class HostFrame:
+    """A page-locked [H, W] uint32 frame from luma_hip_host_alloc, as a numpy view."""
+
+    def __init__(self, height, width):
+        self._p = C.c_void_p()
+        check(lib().luma_hip_host_alloc(C.byref(self._p), height * width * 4), "luma_hip_host_alloc")
+        buf = (C.c_uint32 * (height * width)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=np.uint32).reshape(height, width)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().luma_hip_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def device_count():
@@ -224,9 +249,9 @@ class Context:
     def rows(self):
         return self.row_end - self.row_begin
 
-    def render(self, params, want_stats=True):
-        """luma_hip_render: returns (band uint32 [rows, W], Stats)."""
-        out = np.empty((self.rows, self.width), dtype=np.uint32)
+    def render(self, params, want_stats=True, out=None):
+        """luma_hip_render: returns (band uint32 [rows, W], Stats).  `out`: a frame to fill in place."""
+        out = np.empty((self.rows, self.width), dtype=np.uint32) if out is None else out
         st = Stats()
         check(lib().luma_hip_render(self._h, C.byref(params), _u32p(out), C.byref(st) if want_stats else None),
               "luma_hip_render")
@@ -312,8 +337,8 @@ class Group:
         check(lib().luma_hip_group_read_accum(self._h, _f32p(out)), "luma_hip_group_read_accum")
         return out
 
-    def render(self, params, want_stats=True):
-        out = np.empty((self.height, self.width), dtype=np.uint32)
+    def render(self, params, want_stats=True, out=None):
+        out = np.empty((self.height, self.width), dtype=np.uint32) if out is None else out
         st = Stats()
         check(lib().luma_hip_group_render(self._h, C.byref(params), _u32p(out), C.byref(st) if want_stats else None),
               "luma_hip_group_render")

@@ -672,6 +672,19 @@ int luma_hip_group_read_accum(luma_group* g, float* rgb_host)
     return LUMA_OK;
 }
 
+int luma_hip_host_alloc(void** out, size_t bytes)
+{
+    if (!out || bytes == 0) { return fail(LUMA_E_ARG, "luma_hip_host_alloc", "null pointer or zero size"); }
+    *out = nullptr;
+    LUMA_HIP_TRY(hipHostMalloc(out, bytes, hipHostMallocPortable));
+    return LUMA_OK;
+}
+
+void luma_hip_host_free(void* p)
+{
+    if (p) { (void)hipHostFree(p); }
+}
+
 int luma_hip_target_device(luma_ctx* ctx, uint32_t** target_dev)
 {
     if (!ctx || !target_dev) { return fail(LUMA_E_ARG, "luma_hip_target_device", "null argument"); }

@@ -433,6 +433,23 @@ def test_render_frame_scatters_bands_into_one_frame(abi):
         assert_frames_equal(frame, want, f"render_frame striped={striped}")
 
 
+def test_page_locked_host_frame(abi):
+    """luma_hip_host_alloc: the same pixels arrive in a page-locked frame as in a pageable one."""
+    W, H = 128, 72
+    kw = dict(spp=2, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    want, _, _ = hip_render(abi, abi.default_scene(), abi.default_camera(W, H), W, H, **kw)
+    with abi.HostFrame(H, W) as hf, abi.Group([0, 0]) as g:
+        hf.array[:] = 0
+        g.set_scene(abi.default_scene())
+        g.set_camera(abi.default_camera(W, H))
+        g.set_frame(W, H)
+        g.render(abi.make_params(W, H, **kw), out=hf.array)
+        assert_frames_equal(hf.array.copy(), want, "page-locked frame")
+    with pytest.raises(abi.LumaError) as e:
+        abi.HostFrame(0, 16)
+    assert e.value.code == abi.E_ARG
+
+
 def test_group_errors(abi):
     with pytest.raises(abi.LumaError) as e:
         abi.Group([])
