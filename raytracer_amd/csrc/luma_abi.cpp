@@ -238,11 +238,35 @@ int collect_stats(luma_ctx* ctx, hipStream_t stream, luma_stats* stats)
 
 // Copies the band in ctx->d_target to its rows of a full host frame: contiguous bands in one
 // copy, interleaved stripes as one strided copy (chunk q of `stripe` rows lands `pitch` rows apart).
-int copy_band_to_frame(const luma_ctx* ctx, uint32_t* frame_host)
+// True for memory the runtime knows as page-locked host memory (hipHostMalloc / hipHostRegister).
+bool is_page_locked(const void* p)
+{
+    hipPointerAttribute_t attr{};
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();                                 // plain malloc memory: not an error here
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+// Copies the band in ctx->d_target to its rows of a full host frame: contiguous bands in one
+// copy, interleaved stripes as one strided copy (chunk q of `stripe` rows lands `pitch` rows apart).
+// async: enqueued on ctx->stream behind the render, the caller synchronises the stream (only worth
+// it into a page-locked frame: pageable async copies are staged and several times slower).
+int copy_band_to_frame(const luma_ctx* ctx, uint32_t* frame_host, bool async)
 {
     const size_t row_bytes = static_cast<size_t>(ctx->width) * sizeof(uint32_t);
     uint32_t* dst = frame_host + static_cast<size_t>(ctx->row_begin) * ctx->width;
-    if (ctx->stripe == ctx->rows) {
+    const bool one_piece = ctx->stripe == ctx->rows;
+    if (async) {
+        if (one_piece) {
+            LUMA_HIP_TRY(hipMemcpyAsync(dst, ctx->d_target, ctx->rows * row_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        } else {
+            LUMA_HIP_TRY(hipMemcpy2DAsync(dst, ctx->pitch * row_bytes, ctx->d_target, ctx->stripe * row_bytes,
+                                          ctx->stripe * row_bytes, ctx->rows / ctx->stripe, hipMemcpyDeviceToHost,
+                                          ctx->stream));
+        }
+    } else if (one_piece) {
         LUMA_HIP_TRY(hipMemcpy(dst, ctx->d_target, ctx->rows * row_bytes, hipMemcpyDeviceToHost));
     } else {
         LUMA_HIP_TRY(hipMemcpy2D(dst, ctx->pitch * row_bytes, ctx->d_target, ctx->stripe * row_bytes,
@@ -506,7 +530,7 @@ int luma_hip_render_frame(luma_ctx* ctx, const luma_params* params, uint32_t* fr
     if (int rc = enqueue_render(ctx, params, ctx->d_target, ctx->stream)) { return rc; }
     LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const auto t1 = std::chrono::steady_clock::now();
-    if (int rc = copy_band_to_frame(ctx, frame_host)) { return rc; }
+    if (int rc = copy_band_to_frame(ctx, frame_host, false)) { return rc; }
     const auto t2 = std::chrono::steady_clock::now();
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
@@ -628,15 +652,23 @@ int luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* fr
         if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
         if (int rc = enqueue_render(c, params, c->d_target, c->stream)) { return rc; }
     }
-    double copy_ms = 0.0;
-    for (luma_ctx* c : g->ctx) {                                   // ... and hands it over as it finishes
+    // ... and hands it over as it finishes: into a page-locked frame the copies queue behind the
+    // kernels and run at the same time on every device's link, else one blocking copy per device.
+    const bool async = is_page_locked(frame_host);
+    for (luma_ctx* c : g->ctx) {
         DeviceScope scope(c->device);
         if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
-        LUMA_HIP_TRY(hipStreamSynchronize(c->stream));
-        const auto c0 = std::chrono::steady_clock::now();
-        if (int rc = copy_band_to_frame(c, frame_host)) { return rc; }
-        copy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count();
+        if (!async) { LUMA_HIP_TRY(hipStreamSynchronize(c->stream)); }
+        if (int rc = copy_band_to_frame(c, frame_host, async)) { return rc; }
     }
+    if (async) {
+        for (luma_ctx* c : g->ctx) {
+            DeviceScope scope(c->device);
+            if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+            LUMA_HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+    }
+    const auto t1 = std::chrono::steady_clock::now();
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         for (luma_ctx* c : g->ctx) {
@@ -648,7 +680,9 @@ int luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* fr
             stats->rays += one.rays;
             stats->sphere_tests += one.sphere_tests;
         }
-        stats->gather_ms = copy_ms;
+        // kernels and copies of different devices overlap: the copy share is what the slowest kernel leaves
+        const double all_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        stats->gather_ms = all_ms > stats->kernel_ms ? all_ms - stats->kernel_ms : 0.0;
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return LUMA_OK;
