@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include <charconv>
+#include <cstdlib>
 #include <functional>
 #include <unordered_map>
 
@@ -23,6 +24,17 @@ bool whole_number(const std::string& text, T& out, int base = 10)
     if (base == 16 && text.size() > 2 && text[0] == '0' && (text[1] == 'x' || text[1] == 'X')) { first += 2; }
     const auto [ptr, ec] = std::from_chars(first, last, out, base);
     return ec == std::errc() && ptr == last && first != last;
+}
+
+// Whole-string decimal real (strtof accepts more: hex floats, inf, nan; those are refused).
+bool real_number(const std::string& text, float& out)
+{
+    if (text.empty() || text.find_first_not_of("+-0123456789.eE") != std::string::npos) { return false; }
+    char* end = nullptr;
+    const float v = std::strtof(text.c_str(), &end);
+    if (end != text.c_str() + text.size()) { return false; }
+    out = v;
+    return true;
 }
 
 using Setter = std::function<bool(const std::string&)>;   // false: value not understood
@@ -83,6 +95,23 @@ void Arguments::parse(const std::vector<std::string>& arguments)
             const bool hex = v.size() > 2 && v[0] == '0' && (v[1] == 'x' || v[1] == 'X');
             if (!whole_number(v, s, hex ? 16 : 10)) { return false; }
             _options.seed = s; return true; } } },
+        { "pos",     { "camera position", [](const std::string& v) {
+            float xyz[3];
+            std::size_t at = 0;
+            for (int i = 0; i < 3; i++) {
+                const std::size_t comma = std::min(v.find(',', at), v.size());
+                if (!real_number(v.substr(at, comma - at), xyz[i]) || (i < 2 && comma == v.size())) { return false; }
+                at = comma + 1;
+            }
+            if (at <= v.size()) { return false; }                  // a fourth component
+            std::copy(xyz, xyz + 3, _options.pos);
+            _options.have_pose = true; return true; } } },
+        { "pitch",   { "camera pitch", [](const std::string& v) {
+            if (!real_number(v, _options.pitch)) { return false; }
+            _options.have_pose = true; return true; } } },
+        { "yaw",     { "camera yaw", [](const std::string& v) {
+            if (!real_number(v, _options.yaw)) { return false; }
+            _options.have_pose = true; return true; } } },
         { "frames",  { "frame count", number_into(_options.frames) } },
         { "flags",   { "flags", number_into(_options.flags) } },
         { "shm",     { "shared-memory name", [](const std::string& v) { if (v.empty()) { return false; } _options.shm = v; return true; } } },

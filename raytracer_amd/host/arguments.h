@@ -1,5 +1,6 @@
 // arguments.h -- luma::Options / luma::Arguments as in the reference (arguments.h:9-49), plus
-// the flags this backend adds: --backend, --gpus, --devices, --seed, --frames, --output, --flags, --shm.
+// the flags this backend adds: --backend, --gpus, --devices, --seed, --frames, --output, --flags, --shm,
+// --pos/--pitch/--yaw.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -26,6 +27,8 @@ struct Options {
     std::uint32_t frames = 1;       // headless: frames to accumulate before writing the image
     std::uint32_t flags = 0;        // LUMA_FLAG_* (0 == reference behaviour)
     std::string output = "output.ppm";
+    bool have_pose = false;         // headless stand-in for the fly-cam keys (Camera.cpp:107-129):
+    float pos[3] = { 0.f, 0.f, 0.f }, pitch = 0.f, yaw = 0.f;   //   --pos=x,y,z --pitch=rad --yaw=rad
     std::string shm;                // headless: POSIX shared-memory name that receives every frame ("" = off)
 };
 

@@ -73,6 +73,10 @@ int main(int argc, char** argv)
     luma::log(std::to_string(luma::_options.width) + "x" + std::to_string(luma::_options.height) + " on "
               + std::to_string(luma::_options.gpus) + " device(s)");
     luma::Renderer renderer{};
+    if (luma::_options.have_pose) {      // applied by Camera::update in the first render_to, as a key press would be
+        renderer.camera.move_to({ luma::_options.pos[0], luma::_options.pos[1], luma::_options.pos[2] },
+                                luma::_options.pitch, luma::_options.yaw);
+    }
     const std::size_t pixels = static_cast<std::size_t>(luma::_options.width) * luma::_options.height;
     // main.cpp:259 has `new std::uint32_t[width * height]`; a page-locked frame lets the devices
     // write it by DMA (0.15 ms instead of 0.5-1.1 ms per 1080p frame, tools/hostpath_timing.py)

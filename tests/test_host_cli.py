@@ -38,6 +38,10 @@ def test_parser_space_and_equals_forms():
     assert r.returncode == 2 and "unrecognized" not in r.stdout
     r = run("--devices=0,,1", "--context=directx")
     assert "unrecognized device list `0,,1`" in r.stdout
+    r = run("--pos=1,2", "--pos=1,2,3,4", "--pitch=abc", "--pos=1.5,-2e0,3", "--yaw=0.5", "--context=directx")
+    assert "unrecognized camera position `1,2`" in r.stdout and "unrecognized camera position `1,2,3,4`" in r.stdout
+    assert "unrecognized camera pitch `abc`" in r.stdout
+    assert "`1.5,-2e0,3`" not in r.stdout and "camera yaw" not in r.stdout
     r = run("--gpus=9", "--context=directx")
     assert "unrecognized gpu count `9`" in r.stdout
     r = run("--width=0", "--height=10")
@@ -78,6 +82,22 @@ def test_headless_several_devices_one_frame(tmp_path, oracle, sel, H):
     assert f"on {sel.count(',') + 1} device(s)" in r.stdout
     want, _, _ = oracle.render(oracle.default_scene(), oracle.camera(W, H),
                                oracle.make_params(W, H, seed=0x4C554D41, spp=4, bounces=5, mode=1, flags=0))
+    ref = tmp_path / "oracle.ppm"
+    assert oracle.export_ppm(want, str(ref)) == 0
+    assert out.read_bytes() == ref.read_bytes()
+
+
+@pytest.mark.gpu
+def test_headless_posed_camera(tmp_path, oracle):
+    """--pos/--pitch/--yaw go through Camera::move_to -> update -> the camera.moved branch
+    (Renderer.cpp:377-390) before the first frame."""
+    W, H = 96, 54
+    out = tmp_path / "frame.ppm"
+    r = run("--backend=hip", f"--width={W}", f"--height={H}", "--mode=pathtrace", "--bounces=5", "--frames=3",
+            "--pos=2,-1,4", "--pitch=0.2", "--yaw", "0.35", f"--output={out}")
+    assert r.returncode == 0, r.stdout + r.stderr
+    want, _, _ = oracle.render(oracle.default_scene(), oracle.camera_pose(W, H, (2.0, -1.0, 4.0), 0.2, 0.35),
+                               oracle.make_params(W, H, seed=0x4C554D41, spp=3, bounces=5, mode=1, flags=0))
     ref = tmp_path / "oracle.ppm"
     assert oracle.export_ppm(want, str(ref)) == 0
     assert out.read_bytes() == ref.read_bytes()
