@@ -22,7 +22,7 @@ static constexpr size_t kMaxSceneLdsBytes = 158 * 1024;
 
 // Scenes with at least this many spheres (and whose padded records fit in LDS) use the
 // sphere-parallel scan (render_kernel_sp); smaller ones the ray-per-lane scan.
-static constexpr uint32_t kSphereParallelMin = 192;
+static constexpr uint32_t kSphereParallelMin = 320;   // measured crossover (tools/scene_size_sweep.py)
 
 // The ray counter is kCounterSlots 64-bit slots, one per 64-byte line (stride in u64).
 static constexpr uint32_t kCounterSlots = 256;

@@ -511,7 +511,7 @@ LUMA_DEV uint32_t wave_min_u32(uint32_t v)
 }
 
 // Scan for lane `j`'s ray over records laid out [batch][lane] in LDS; n_pad is a multiple of
-// 256 and the padding records are NaN (never a candidate).  All 64 lanes must call this.
+// 64 and the padding records are NaN (never a candidate).  All 64 lanes must call this.
 template <bool CAM_ORIGIN>
 LUMA_DEV unsigned long long wave_scan_one(const float4* __restrict__ rec, uint32_t n_pad, uint32_t lane,
                                           float ox, float oy, float oz, float dx, float dy, float dz, float a)
@@ -538,7 +538,8 @@ LUMA_DEV unsigned long long wave_scan_one(const float4* __restrict__ rec, uint32
         }
     };
 
-    for (uint32_t base = 0; base < n_pad; base += 256) {
+    uint32_t base = 0;
+    for (; base + 256 <= n_pad; base += 256) {
         const float4 s0 = rec[base + lane], s1 = rec[base + 64 + lane];
         const float4 s2 = rec[base + 128 + lane], s3 = rec[base + 192 + lane];
         float b0, d0, b1, d1, b2, d2, b3, d3;
@@ -549,6 +550,11 @@ LUMA_DEV unsigned long long wave_scan_one(const float4* __restrict__ rec, uint32
             consider(b0, d0, base + lane); consider(b1, d1, base + 64 + lane);
             consider(b2, d2, base + 128 + lane); consider(b3, d3, base + 192 + lane);
         }
+    }
+    for (; base < n_pad; base += 64) {                           // up to three more batches of 64
+        float b, d;
+        test(rec[base + lane], b, d);
+        consider(b, d, base + lane);
     }
 
     // Lexicographic min of (t, index) over the wave, in registers (DPP + readlane, no LDS round
@@ -596,7 +602,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     // [0,n_pad): camera-origin records; [n_pad,2 n_pad): general records; padding = NaN
     extern __shared__ float4 lds_rec[];
     const uint32_t n = A.n_spheres;
-    const uint32_t n_pad = (n + 255u) & ~255u;
+    const uint32_t n_pad = (n + 63u) & ~63u;
     {
         const float qnan = __builtin_nanf("");
         const float4 never = make_float4(qnan, qnan, qnan, qnan);
@@ -817,7 +823,7 @@ __global__ void generate_rays_kernel(const RenderArgs A, float* __restrict__ ray
 bool sphere_parallel_scene(uint32_t n_spheres)
 {
     return n_spheres >= kSphereParallelMin
-        && (size_t)((n_spheres + 255u) & ~255u) * 2u * sizeof(float4) <= kMaxSceneLdsBytes;
+        && (size_t)((n_spheres + 63u) & ~63u) * 2u * sizeof(float4) <= kMaxSceneLdsBytes;
 }
 
 uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres)
@@ -855,17 +861,19 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     const bool noise = !(args.flags & FLAG_NOISE_OFF), from_hit = (args.flags & FLAG_ORIGIN_FROM_HIT) != 0;
     using kernel_t = void (*)(const RenderArgs);
 
-    // Large scenes: sphere-parallel scan, records (padded to 256) in LDS.
-    const size_t sp_bytes = (size_t)((n + 255u) & ~255u) * 2u * sizeof(float4);
+    // Large scenes: sphere-parallel scan, records (padded to 64) in LDS.
+    const size_t sp_bytes = (size_t)((n + 63u) & ~63u) * 2u * sizeof(float4);
     kernel_t k;
     size_t lds;
     int waves, split = 1;
     const bool sphere_parallel = sphere_parallel_scene(n);
     if (sphere_parallel) {
-        // 8 workgroups of 4 waves fill a CU (32 waves) only while each needs <= 20 KiB of the
-        // 160 KiB LDS; beyond that use 16-wave workgroups (2 per CU up to 80 KiB, then 1).
+        // The kernel needs ~90 VGPRs, so a SIMD holds 5 waves: five 4-wave workgroups per CU
+        // (20 waves) fit while each needs <= 32 KiB of the 160 KiB LDS; beyond that one 16-wave
+        // workgroup per CU (a second would need 8 waves per SIMD).  640 -> 641 spheres cost 19 %
+        // when the switch sat at 20 KiB (tools/scene_size_sweep.py).
         lds = sp_bytes;
-        waves = lds > 20 * 1024 ? 16 : 4;
+        waves = lds > 32 * 1024 ? 16 : 4;
 #define LUMA_SP(W) { { render_kernel_sp<kTileW, W, false, false>, render_kernel_sp<kTileW, W, false, true> }, \
                      { render_kernel_sp<kTileW, W, true, false>,  render_kernel_sp<kTileW, W, true, true> } }
         static const kernel_t sp_table[2][2][2] = { LUMA_SP(4), LUMA_SP(16) };

@@ -259,7 +259,7 @@ def test_flags(abi, oracle, flags):
 def test_rgba8_pack_is_a_byte_permutation(abi):
     """LUMA_FLAG_PACK_RGBA8 with CLAMP_PACK: bytes R,G,B,255 of the same channels as ::RGB's
     0x00RRGGBB (Renderer.cpp:44-55), sphere-parallel kernel included."""
-    for scene, W, H in [(abi.default_scene(), 96, 54), (abi.synthetic_scene(256), 40, 24)]:
+    for scene, W, H in [(abi.default_scene(), 96, 54), (abi.synthetic_scene(384), 40, 24)]:
         kw = dict(spp=2, bounces=5, paths=1, samples=1, mode=1, seed=SEED)
         ref, _, _ = hip_render(abi, scene, abi.default_camera(W, H), W, H, flags=abi.FLAG_CLAMP_PACK, **kw)
         got, _, _ = hip_render(abi, scene, abi.default_camera(W, H), W, H,
@@ -284,13 +284,16 @@ def test_posed_camera_render(abi, oracle):
 
 @pytest.mark.parametrize("n,W,H,spp,flags,paths", [
     (300, 96, 54, 2, 0, 1), (4096, 64, 36, 1, 0, 1), (6000, 48, 27, 1, 0, 1),
-    (191, 40, 24, 2, 0, 1), (192, 40, 24, 2, 0, 1), (257, 33, 19, 2, 0, 2), (1000, 50, 30, 2, 2, 1),
-    (640, 37, 21, 1, 1, 1), (641, 37, 21, 2, 1 | 2, 0), (4864, 20, 12, 1, 0, 1), (4865, 20, 12, 1, 0, 1),
+    (191, 40, 24, 2, 0, 1), (257, 33, 19, 2, 0, 2), (319, 40, 24, 2, 0, 1), (320, 40, 24, 2, 0, 1),
+    (321, 33, 19, 1, 0, 2), (449, 33, 19, 1, 2, 1), (1000, 50, 30, 2, 2, 1),
+    (640, 37, 21, 1, 1, 1), (1024, 37, 21, 2, 1 | 2, 0), (1025, 37, 21, 1, 0, 1), (4864, 20, 12, 1, 0, 1), (4865, 20, 12, 1, 0, 1),
+    (5056, 20, 12, 1, 0, 1), (5057, 20, 12, 1, 0, 1),
 ])
 def test_synthetic_scene(abi, oracle, n, W, H, spp, flags, paths):
-    """Config #5's scene generator.  n < 192: ray-per-lane scan from LDS; 192 <= n <= 4864:
-    sphere-parallel scan (4-wave workgroups up to 640 spheres, 16-wave beyond; n=4096 fills
-    128 KiB of LDS); larger n: ray-per-lane scan from global memory."""
+    """Config #5's scene generator.  n < 320: ray-per-lane scan from LDS; 320 <= n <= 5056:
+    sphere-parallel scan over records padded to batches of 64 (four batches per trip, then up to
+    three single ones; 4-wave workgroups up to 1024 spheres, 16-wave beyond; n=4096 fills 128 KiB
+    of LDS, n=5056 all 158); larger n: ray-per-lane scan from global memory."""
     kw = dict(spp=spp, bounces=5, paths=paths, samples=1, mode=1, flags=flags, seed=SEED)
     got, acc, st = hip_render(abi, abi.synthetic_scene(n), abi.default_camera(W, H), W, H, **kw)
     want, wacc, ost = oracle.render(oracle.synthetic_scene(n), oracle.camera(W, H), oracle.make_params(W, H, **kw))
@@ -345,7 +348,7 @@ def test_bands_equal_full_frame(abi, oracle, nbands):
     assert rays == fst.rays
 
 
-@pytest.mark.parametrize("W,H,stripe,n,scene_n", [(96, 48, 3, 4, 0), (64, 120, 15, 8, 0), (50, 32, 4, 2, 300)])
+@pytest.mark.parametrize("W,H,stripe,n,scene_n", [(96, 48, 3, 4, 0), (64, 120, 15, 8, 0), (50, 32, 4, 2, 384)])
 def test_interleaved_stripes_equal_full_frame(abi, oracle, W, H, stripe, n, scene_n):
     """luma_hip_set_frame_striped: rank r renders rows with (y / stripe) % n == r; the stripes put
     back in order are bit-identical to the one-device frame (and to the oracle)."""
@@ -379,7 +382,7 @@ def test_interleaved_stripes_equal_full_frame(abi, oracle, W, H, stripe, n, scen
     (96, 60, [0, 0], 0),          # 60 % (15*2) == 0: interleaved stripes
     (96, 60, [0, 0, 0], 0),       # 60 % 45 != 0: contiguous bands of 20 rows
     (70, 53, [0, 0, 0, 0], 0),    # ragged bands 13,13,13,14
-    (48, 120, [0] * 8, 300),      # eight stripes-of-15 bands, sphere-parallel kernel
+    (48, 120, [0] * 8, 384),      # eight stripes-of-15 bands, sphere-parallel kernel
     (64, 36, [0], 0),             # a group of one
 ])
 def test_group_renders_whole_frame(abi, oracle, W, H, ids, scene_n):
