@@ -56,10 +56,19 @@ LUMA_DEV f3 fma3(f3 a, float s, f3 c) { return mk3(fma_(a.x, s, c.x), fma_(a.y, 
 
 // exp() of the contract: Cody-Waite by ln2, degree-5 polynomial, 2^k through the exponent
 // field.  Stands in for std::exp at Renderer.cpp:61 and :427.
+LUMA_DEV float luma_expf_core(float x);
 LUMA_DEV float luma_expf(float x)
 {
     if (!(x >= -87.0f)) { return (x != x) ? x : 0.0f; }
     if (x > 88.0f) { return __builtin_inff(); }
+    return luma_expf_core(x);
+}
+
+// ::tonemap, Renderer.cpp:57-70: 1 - exp(-c) per channel.  One range test covers the three
+// channels (radiance is 0..a few units, so the out-of-range branches of luma_expf never run);
+// anything outside takes the checked form.
+LUMA_DEV float luma_expf_core(float x)                           // luma_expf for -87 <= x <= 88
+{
     float kf = __builtin_rintf(x * 1.44269504088896341f);
     float r = fma_(kf, -0.693359375f, x);
     r = fma_(kf, 2.12194440e-4f, r);
@@ -74,6 +83,15 @@ LUMA_DEV float luma_expf(float x)
     int k = (int)kf;
     float s = __builtin_bit_cast(float, (uint32_t)(k + 127) << 23);
     return e * s;
+}
+LUMA_DEV f3 tonemap3(f3 c)
+{
+    // (fmin/fmax drop a NaN operand: a NaN channel may take either form, and is NaN after both)
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(c.x, c.y), c.z), lo = __builtin_fminf(__builtin_fminf(c.x, c.y), c.z);
+    if (__builtin_expect(hi <= 87.0f && lo >= -88.0f, 1)) {
+        return mk3(1.0f - luma_expf_core(-c.x), 1.0f - luma_expf_core(-c.y), 1.0f - luma_expf_core(-c.z));
+    }
+    return mk3(1.0f - luma_expf(-c.x), 1.0f - luma_expf(-c.y), 1.0f - luma_expf(-c.z));
 }
 
 // pcg3d (Jarzynski & Olano 2020) over (pixel, sample, slot) ^ keys: the counter RNG.
@@ -226,6 +244,15 @@ LUMA_DEV Hit finish_hit(const float4* __restrict__ rec_gen, int idx, f3 origin, 
     return h;
 }
 
+// ::RGB's shift-and-OR (Renderer.cpp:48-52), or the byte order R,G,B,255 for PACK_RGBA8.
+LUMA_DEV uint32_t pack_pixel(int r, int g, int b, uint32_t flags)
+{
+    if (flags & FLAG_PACK_RGBA8) {
+        return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | 0xFF000000u;
+    }
+    return ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;
+}
+
 // Wave-level sum of a per-lane counter, one atomic per wave.  The counter is split over
 // kCounterSlots cache lines picked by workgroup id: tens of thousands of waves adding into ONE
 // address serialise at the memory side (0.3 ms at 1080p), spread over 256 lines they do not.
@@ -273,15 +300,6 @@ enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 // accumulator as before; the others park each frame's colour in a global scratch plane, and
 // after a workgroup barrier lane 0 adds those in frame order, so the float sum is still the
 // reference's ((acc + f0) + f1) + ... (Renderer.cpp:457-458), bit for bit.
-// ::RGB's shift-and-OR (Renderer.cpp:48-52), or the byte order R,G,B,255 for PACK_RGBA8.
-__device__ __forceinline__ uint32_t pack_pixel(int r, int g, int b, uint32_t flags)
-{
-    if (flags & FLAG_PACK_RGBA8) {
-        return (uint32_t)r | ((uint32_t)g << 8) | ((uint32_t)b << 16) | 0xFF000000u;
-    }
-    return ((uint32_t)r << 16) | ((uint32_t)g << 8) | (uint32_t)b;
-}
-
 template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT>
 __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 {
@@ -359,15 +377,14 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
     if (live) {
         if (k == 0) { acc_r = A.acc[0][local]; acc_g = A.acc[1][local]; acc_b = A.acc[2][local]; }
 
-        // per-lane path state
-        uint32_t s = s_first, bounce = 0;
+        // per-lane path state (slot == bounce * slots: first RNG slot of the bounce)
+        uint32_t s = s_first, bounce = 0, slot = 0;
         f3 direct = mk3(0.f, 0.f, 0.f);
         f3 dir = dir0;                                           // :293
         f3 origin = campos;                                      // :294, :303
 
         while (s < spp) {
             const uint32_t sample = A.frame_index + s;
-            const uint32_t slot = bounce * slots;
             f3 dn = dir;
             if (NOISE) { dn = add3(dir, rng_vec3(A, pixel, sample, slot, -blur, blur)); }   // :118-119, :302
             else       { dn = add3(dir, mk3(0.f, 0.f, 0.f)); }
@@ -430,13 +447,12 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
                     const float k = 2.0f * dot3(dn, nrm);        // fx::reflect, :229
                     dir = fma3(nrm, -k, dn);                     // :359
                     if (FROM_HIT) { origin = fma3(hit.normal, .001f, hit.pos); }   // :221-222
+                    slot += slots;
                 }
             }
 
             if (path_ends) {
-                f3 result = mk3(1.0f - luma_expf(-direct.x), 1.0f - luma_expf(-direct.y),
-                                1.0f - luma_expf(-direct.z));    // :362, :57-70
-                if (gainf != 1.0f) { result = scale3(result, gainf); }   // :452
+                const f3 result = scale3(tonemap3(direct), gainf);    // :362, :57-70; :452 (x * 1.0f is x)
                 if (SPLIT == 1 || k == 0) {
                     acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
                 } else {
@@ -445,6 +461,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
                 }
                 s++;
                 bounce = 0;
+                slot = 0;
                 direct = mk3(0.f, 0.f, 0.f);
                 dir = dir0;
                 origin = campos;
@@ -762,9 +779,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         }
 
         if (active && path_ends) {
-            f3 result = mk3(1.0f - luma_expf(-direct.x), 1.0f - luma_expf(-direct.y),
-                            1.0f - luma_expf(-direct.z));        // :362, :57-70
-            if (gainf != 1.0f) { result = scale3(result, gainf); }   // :452
+            const f3 result = scale3(tonemap3(direct), gainf);   // :362, :57-70; :452 (x * 1.0f is x)
             acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
             s++;
             bounce = 0;
