@@ -230,6 +230,11 @@ def main():
             "frame_ms": ms_per_step,
             "msamples_per_s": WIDTH * (HEIGHT // (a.emulate_world or 1)) * SPP * a.steps / dt / 1e6,
             "rays_per_step": rays_per_step,
+            # the reference traces the noise-free DOF ray once per frame (Renderer.cpp:416); the kernels
+            # trace it once per call and reuse it, so `value` counts (spp-1)*W*H fewer rays per step than
+            # the reference's own loop (and the oracle in cpu_baseline) would for the same frames
+            "reference_equivalent_mrays_per_s": (rays_per_step + (SPP - 1) * WIDTH * (HEIGHT if not a.emulate_world else (y1 - y0)))
+                                                * a.steps / dt / 1e6,
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
