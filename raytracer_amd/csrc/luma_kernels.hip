@@ -473,9 +473,22 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 
     if (live && k == 0) {
         if (SPLIT > 1) {
-            for (uint32_t f = s_park; f < spp_all; f++) {        // the other lanes' frames, in frame order
+            // the other lanes' frames, added in frame order (:457-458); eight frames' loads are
+            // issued together so the loop waits for memory once per eight frames, not per frame
+            uint32_t f = s_park;
+            for (; f + 8u <= spp_all; f += 8u) {
+                float pr[8], pg[8], pb[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float* park = A.split_scratch + (size_t)(f + j - s_park) * 3u * npix + local;
+                    pr[j] = park[0]; pg[j] = park[npix]; pb[j] = park[2 * npix];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) { acc_r += pr[j]; acc_g += pg[j]; acc_b += pb[j]; }
+            }
+            for (; f < spp_all; f++) {
                 const float* park = A.split_scratch + (size_t)(f - s_park) * 3u * npix + local;
-                acc_r += park[0]; acc_g += park[npix]; acc_b += park[2 * npix];   // :457-458
+                acc_r += park[0]; acc_g += park[npix]; acc_b += park[2 * npix];
             }
         }
         A.acc[0][local] = acc_r; A.acc[1][local] = acc_g; A.acc[2][local] = acc_b;
@@ -844,9 +857,10 @@ bool sphere_parallel_scene(uint32_t n_spheres)
 uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres)
 {
     if (sphere_parallel_scene(n_spheres)) { return 1; }
-    // measured on MI355X, 1080p x 64 spp bands: 2 lanes per pixel win below ~800k pixels
-    // (0.80 -> 0.70 ms at 518k, 0.56 -> 0.41 ms at 259k), 4 only on very small bands
-    uint32_t split = band_pixels >= 800000 ? 1u : band_pixels >= 100000 ? 2u : 4u;
+    // measured on MI355X, bands of the 1080p x 64 spp frame (kernel ms for 1 / 2 / 4 lanes per pixel):
+    // 2.07M px 2.06 / 2.15 / 2.54, 1.04M px 1.16 / 1.13 / 1.26, 518k px 0.65 / 0.63 / 0.64,
+    // 259k px 0.49 / 0.37 / 0.35
+    uint32_t split = band_pixels >= 1500000 ? 1u : band_pixels >= 400000 ? 2u : 4u;
     while (split > spp) { split >>= 1; }
     return split ? split : 1u;
 }
