@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libluma_hip.so")
+LIB_PATH = os.environ.get("LUMA_HIP_LIB") or os.path.join(_PKG, "libluma_hip.so")   # override: A/B runs of two builds
 
 OK, E_ARG, E_HIP, E_NOMEM, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5
 MODE_RAYTRACE, MODE_PATHTRACE = 0, 1
