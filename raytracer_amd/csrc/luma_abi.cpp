@@ -197,7 +197,7 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
     luma::RenderArgs args = make_args(ctx, p, target_dev);
     args.split = luma::choose_split(ctx->band_pixels(), p->spp, ctx->n_spheres);
     if (args.split > 1) {
-        const size_t need = static_cast<size_t>(p->spp - p->spp / args.split) * 3u * ctx->band_pixels() * sizeof(float);
+        const size_t need = static_cast<size_t>(p->spp) * 3u * ctx->band_pixels() * sizeof(float);   // a slot per frame
         if (need > (size_t(2) << 30)) {
             args.split = 1;                                      // not worth 2 GiB of scratch
         } else if (need > ctx->split_bytes) {

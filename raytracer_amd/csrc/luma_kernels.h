@@ -55,7 +55,7 @@ struct RenderArgs {
     float*    acc[3];           // accumulation planes r, g, b
     uint32_t* target;           // 0x00RRGGBB
     // frame splitting (ray-per-lane kernel): lanes per pixel (1, 2 or 4) and the planes where
-    // lanes 1.. park their frames: (spp - spp/split) x 3 x band pixels floats
+    // lanes 1.. park their frames: spp x 3 x band pixels floats (one slot per frame)
     uint32_t  split;
     float*    split_scratch;
     uint32_t* tile_counter;        // sphere-parallel kernel: next wave tile, zeroed before every launch

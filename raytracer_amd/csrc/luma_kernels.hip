@@ -295,11 +295,12 @@ enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 //
 // SPLIT (1, 2 or 4) spreads the frames of one pixel over SPLIT lanes of the same workgroup when
 // the band has too few pixels to fill the GPU (8 GPUs x 1080p leave 259k pixels per GPU for
-// 524k thread slots, and one lane needs ~0.4 ms for 64 frames whatever the band size).  Lane k of
-// a pixel renders frames [k*spp/SPLIT, (k+1)*spp/SPLIT).  Lane 0 adds its frames to the
-// accumulator as before; the others park each frame's colour in a global scratch plane, and
-// after a workgroup barrier lane 0 adds those in frame order, so the float sum is still the
-// reference's ((acc + f0) + f1) + ... (Renderer.cpp:457-458), bit for bit.
+// 524k thread slots, and one lane needs ~0.4 ms for 64 frames whatever the band size).  Lane 0
+// of a pixel adds the frames it renders to the accumulator as before; the others park each
+// frame's colour in a global scratch plane, and after a workgroup barrier lane 0 adds those in
+// frame order, so the float sum is still the reference's ((acc + f0) + f1) + ...
+// (Renderer.cpp:457-458), bit for bit.  Which lane renders which frame is settled at run time
+// (see `claim` below).
 template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT>
 __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 {
@@ -348,6 +349,13 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
     // DOF pre-pass, :416-432.  Noise free, so it is the same for every frame of the call; with
     // SPLIT > 1 lane 0 of the pixel traces it and hands blur and gain to the others through LDS.
     __shared__ float2 dof_shared[SPLIT > 1 ? WPK * 64 : 1];
+    // Frames of a pixel are not dealt out in fixed blocks: its SPLIT lanes claim them one at a
+    // time from one LDS word (low half: claims from the front, by lane 0; high half: claims from
+    // the back, by the others).  Lane 0 takes frames 0, 1, 2, ... and adds them directly, the
+    // others take spp-1, spp-2, ... and park them; a claim is good while front + back < spp, so
+    // the two ends meet wherever the lanes' luck puts them and no lane waits on a slower sibling.
+    __shared__ uint32_t claim[SPLIT > 1 ? WPK * 64 : 1];
+    if (SPLIT > 1 && k == 0) { claim[wv * 64 + lane] = 0u; }
     f3 dir0 = mk3(0.f, 0.f, -1.f);
     float blur = 0.f, gainf = 1.f;
     if (live) { dir0 = camera_ray(A, x, y); }                    // camera.rays[index], :413
@@ -370,20 +378,29 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 
     // bounces == 0: the loop at :300 never runs, every sample adds tonemap(0) * gain = +0.
     const uint32_t spp_all = A.bounces ? A.spp : 0u;
-    const uint32_t s_first = k * spp_all / SPLIT, spp = (k + 1u) * spp_all / SPLIT;   // this lane's frames
-    const uint32_t s_park = spp_all / SPLIT;                     // frames >= s_park go through the scratch planes
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
+    uint32_t front = 0;                                          // frames lane 0 added itself: [0, front)
 
     if (live) {
         if (k == 0) { acc_r = A.acc[0][local]; acc_g = A.acc[1][local]; acc_b = A.acc[2][local]; }
 
         // per-lane path state (slot == bounce * slots: first RNG slot of the bounce)
-        uint32_t s = s_first, bounce = 0, slot = 0;
+        uint32_t s = 0, bounce = 0, slot = 0;
         f3 direct = mk3(0.f, 0.f, 0.f);
         f3 dir = dir0;                                           // :293
         f3 origin = campos;                                      // :294, :303
 
-        while (s < spp) {
+        // next frame of this lane: s, or false when the pixel has none left
+        auto next_frame = [&]() -> bool {
+            const uint32_t old = atomicAdd(&claim[wv * 64 + lane], k == 0 ? 1u : 0x10000u);
+            const uint32_t f = old & 0xFFFFu, b = old >> 16;
+            if (f + b >= spp_all) { return false; }
+            s = (k == 0) ? f : spp_all - 1u - b;
+            return true;
+        };
+        bool have = (SPLIT == 1) ? true : next_frame();          // SPLIT == 1: plainly frames 0 .. spp-1
+
+        while (SPLIT == 1 ? s < spp_all : have) {
             const uint32_t sample = A.frame_index + s;
             f3 dn = dir;
             if (NOISE) { dn = add3(dir, rng_vec3(A, pixel, sample, slot, -blur, blur)); }   // :118-119, :302
@@ -455,11 +472,12 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
                 const f3 result = scale3(tonemap3(direct), gainf);    // :362, :57-70; :452 (x * 1.0f is x)
                 if (SPLIT == 1 || k == 0) {
                     acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
+                    if (SPLIT > 1) { front++; }
                 } else {
-                    float* park = A.split_scratch + (size_t)(s - s_park) * 3u * npix + local;
+                    float* park = A.split_scratch + (size_t)s * 3u * npix + local;
                     park[0] = result.x; park[npix] = result.y; park[2 * npix] = result.z;
                 }
-                s++;
+                if (SPLIT == 1) { s++; } else { have = next_frame(); }
                 bounce = 0;
                 slot = 0;
                 direct = mk3(0.f, 0.f, 0.f);
@@ -475,19 +493,19 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
         if (SPLIT > 1) {
             // the other lanes' frames, added in frame order (:457-458); eight frames' loads are
             // issued together so the loop waits for memory once per eight frames, not per frame
-            uint32_t f = s_park;
+            uint32_t f = front;
             for (; f + 8u <= spp_all; f += 8u) {
                 float pr[8], pg[8], pb[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float* park = A.split_scratch + (size_t)(f + j - s_park) * 3u * npix + local;
+                    const float* park = A.split_scratch + (size_t)(f + j) * 3u * npix + local;
                     pr[j] = park[0]; pg[j] = park[npix]; pb[j] = park[2 * npix];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) { acc_r += pr[j]; acc_g += pg[j]; acc_b += pb[j]; }
             }
             for (; f < spp_all; f++) {
-                const float* park = A.split_scratch + (size_t)(f - s_park) * 3u * npix + local;
+                const float* park = A.split_scratch + (size_t)f * 3u * npix + local;
                 acc_r += park[0]; acc_g += park[npix]; acc_b += park[2 * npix];
             }
         }
@@ -862,6 +880,7 @@ uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres)
     // 259k px 0.49 / 0.37 / 0.35
     uint32_t split = band_pixels >= 1500000 ? 1u : band_pixels >= 400000 ? 2u : 4u;
     while (split > spp) { split >>= 1; }
+    if (spp > 0xFFFFu) { split = 1; }                            // the claim word holds two 16-bit counts
     return split ? split : 1u;
 }
 
