@@ -876,9 +876,9 @@ uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres)
 {
     if (sphere_parallel_scene(n_spheres)) { return 1; }
     // measured on MI355X, bands of the 1080p x 64 spp frame (kernel ms for 1 / 2 / 4 lanes per pixel):
-    // 2.07M px 2.06 / 2.15 / 2.54, 1.04M px 1.16 / 1.13 / 1.26, 518k px 0.65 / 0.63 / 0.64,
-    // 259k px 0.49 / 0.37 / 0.35
-    uint32_t split = band_pixels >= 1500000 ? 1u : band_pixels >= 400000 ? 2u : 4u;
+    // 2.07M px 2.09 / 2.13 / 2.32, 1.04M px 1.17 / 1.11 / 1.17, 518k px 0.66 / 0.61 / 0.60,
+    // 259k px 0.50 / 0.36 / 0.33
+    uint32_t split = band_pixels >= 1500000 ? 1u : band_pixels >= 750000 ? 2u : 4u;
     while (split > spp) { split >>= 1; }
     if (spp > 0xFFFFu) { split = 1; }                            // the claim word holds two 16-bit counts
     return split ? split : 1u;
