@@ -189,8 +189,8 @@ int order_after_previous(luma_ctx* ctx, hipStream_t stream)
     return LUMA_OK;
 }
 
-// Enqueue one render call on `stream`.  Events bracket the render kernel only.
-int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hipStream_t stream)
+// Enqueue one render call on `stream`.  With `timed`, events bracket the render kernel only.
+int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hipStream_t stream, bool timed)
 {
     if (int rc = order_after_previous(ctx, stream)) { return rc; }
     if (int rc = refresh_records(ctx, stream)) { return rc; }
@@ -212,9 +212,11 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
     if (luma::sphere_parallel_scene(ctx->n_spheres)) {
         LUMA_HIP_TRY(hipMemsetAsync(args.tile_counter, 0, sizeof(uint32_t), stream));
     }
-    LUMA_HIP_TRY(hipEventRecord(ctx->ev_begin, stream));
+    // the events are only recorded for calls that report a luma_stats: each is a packet of its own
+    // in the queue and keeps back-to-back launches apart
+    if (timed) { LUMA_HIP_TRY(hipEventRecord(ctx->ev_begin, stream)); }
     LUMA_HIP_TRY(luma::launch_render(args, stream));
-    LUMA_HIP_TRY(hipEventRecord(ctx->ev_end, stream));
+    if (timed) { LUMA_HIP_TRY(hipEventRecord(ctx->ev_end, stream)); }
     ctx->frame_index += p->spp;
     ctx->last_stream = stream;
     ctx->rendered = true;
@@ -488,7 +490,7 @@ int luma_hip_render(luma_ctx* ctx, const luma_params* params, uint32_t* target_h
     if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_render", "hipSetDevice failed"); }
 
     const auto t0 = std::chrono::steady_clock::now();
-    if (int rc = enqueue_render(ctx, params, ctx->d_target, ctx->stream)) { return rc; }
+    if (int rc = enqueue_render(ctx, params, ctx->d_target, ctx->stream, stats != nullptr)) { return rc; }
     LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const auto t1 = std::chrono::steady_clock::now();
     LUMA_HIP_TRY(hipMemcpy(target_host, ctx->d_target, ctx->band_pixels() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -510,7 +512,7 @@ int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* t
     if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_render_device", "hipSetDevice failed"); }
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
     const auto t0 = std::chrono::steady_clock::now();
-    if (int rc = enqueue_render(ctx, params, target_dev ? target_dev : ctx->d_target, s)) { return rc; }
+    if (int rc = enqueue_render(ctx, params, target_dev ? target_dev : ctx->d_target, s, stats != nullptr)) { return rc; }
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         if (int rc = collect_stats(ctx, s, stats)) { return rc; }
@@ -527,7 +529,7 @@ int luma_hip_render_frame(luma_ctx* ctx, const luma_params* params, uint32_t* fr
     if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_render_frame", "hipSetDevice failed"); }
 
     const auto t0 = std::chrono::steady_clock::now();
-    if (int rc = enqueue_render(ctx, params, ctx->d_target, ctx->stream)) { return rc; }
+    if (int rc = enqueue_render(ctx, params, ctx->d_target, ctx->stream, stats != nullptr)) { return rc; }
     LUMA_HIP_TRY(hipStreamSynchronize(ctx->stream));
     const auto t1 = std::chrono::steady_clock::now();
     if (int rc = copy_band_to_frame(ctx, frame_host, false)) { return rc; }
@@ -650,7 +652,7 @@ int luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* fr
     for (luma_ctx* c : g->ctx) {                                   // every device starts its band ...
         DeviceScope scope(c->device);
         if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
-        if (int rc = enqueue_render(c, params, c->d_target, c->stream)) { return rc; }
+        if (int rc = enqueue_render(c, params, c->d_target, c->stream, stats != nullptr)) { return rc; }
     }
     // ... and hands it over as it finishes: into a page-locked frame the copies queue behind the
     // kernels and run at the same time on every device's link, else one blocking copy per device.
