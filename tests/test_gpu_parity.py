@@ -474,6 +474,54 @@ def test_group_errors(abi):
         assert img.shape == (3, 16)
 
 
+def test_one_context_through_scene_camera_and_frame_changes(abi, oracle):
+    """One context reused the way an interactive host would: scenes of every kernel class in turn
+    (ray-per-lane from LDS, sphere-parallel with 4- and 16-wave workgroups, ray-per-lane from global
+    memory), camera moves with and without a reset, frame-size changes, spp changes (the scratch
+    planes of the frame-splitting kernel grow and are reused).  Every frame equals the oracle's."""
+    with abi.Context(0) as ctx:
+        W, H = 72, 40
+        ctx.set_frame(W, H)
+        cam_a, ocam_a = abi.default_camera(W, H), oracle.camera(W, H)
+        ctx.set_camera(cam_a)
+        ref = None
+        steps = [("scene", 0), ("render", 3), ("scene", 400), ("render", 2), ("render", 5), ("scene", 5), ("render", 9),
+                 ("move", (1.0, -0.5, 2.0, 0.1, -0.4)), ("render", 4), ("scene", 1500), ("render", 1),
+                 ("frame", (33, 21)), ("render", 2), ("scene", 5200), ("render", 1), ("scene", 5), ("render", 17),
+                 ("move_noreset", (0.0, 0.0, 1.0, 0.0, 0.2)), ("render", 2)]
+        n, ocam = 0, ocam_a
+        for what, arg in steps:
+            if what == "scene":
+                n = arg
+                scene = abi.default_scene() if n == 5 else abi.synthetic_scene(n) if n else (abi.Sphere * 0)()
+                oscene = oracle.default_scene() if n == 5 else oracle.synthetic_scene(n) if n else (oracle.Sphere * 0)()
+                ctx.set_scene(scene)
+                ctx.reset()
+                ref = oracle.Renderer(oscene, ocam, W, H)
+            elif what in ("move", "move_noreset"):
+                px, py, pz, pitch, yaw = arg
+                ctx.set_camera(abi.camera_from_pose(W, H, (px, py, pz), pitch, yaw))
+                ocam = oracle.camera_pose(W, H, (px, py, pz), pitch, yaw)
+                if what == "move":
+                    ctx.reset()
+                    ref = oracle.Renderer(oscene, ocam, W, H)
+                else:                                   # the accumulation goes on under the new camera
+                    ref.cam = ocam
+            elif what == "frame":
+                W, H = arg
+                ctx.set_frame(W, H)
+                ctx.set_camera(abi.default_camera(W, H))
+                ocam = oracle.camera(W, H)
+                ref = oracle.Renderer(oscene, ocam, W, H)
+            else:
+                kw = dict(spp=arg, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+                got, _ = ctx.render(abi.make_params(W, H, **kw))
+                ref.render(oracle.make_params(W, H, **kw))
+                assert_frames_equal(got, ref.target, f"after {what} {arg}, n={n}")
+                assert np.array_equal(ctx.read_accum().view(np.uint32), ref.accum.view(np.uint32))
+                assert ctx.frame_index() == ref.frame_index
+
+
 # ---- device-resident target (what bench.py times) ------------------------------------
 
 def test_render_device_matches_host_target(abi):
