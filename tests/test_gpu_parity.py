@@ -436,6 +436,58 @@ def test_render_frame_scatters_bands_into_one_frame(abi):
         assert_frames_equal(frame, want, f"render_frame striped={striped}")
 
 
+def test_contexts_driven_from_their_own_threads(abi):
+    """The thread-per-GPU host shape of luma_hip_render_frame: four contexts (here on one device),
+    each driven by its own host thread, fill one frame at the same time, several frames in a row."""
+    import threading
+    W, H, n = 96, 64, 4
+    kw = dict(spp=3, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    params = abi.make_params(W, H, **kw)
+    frames = []
+    with abi.Context(0) as ctx:
+        ctx.set_scene(abi.default_scene())
+        ctx.set_camera(abi.default_camera(W, H))
+        ctx.set_frame(W, H)
+        for _ in range(3):
+            frames.append(ctx.render(params)[0])
+    frame = np.zeros((H, W), dtype=np.uint32)
+    got, errors = [], []
+    start = threading.Barrier(n + 1)
+    step = threading.Barrier(n + 1)
+
+    def worker(rank):
+        try:
+            with abi.Context(0) as c:
+                c.set_scene(abi.default_scene())
+                c.set_camera(abi.default_camera(W, H))
+                c.set_frame(W, H, rank * H // n, (rank + 1) * H // n)
+                start.wait()
+                for _ in range(3):
+                    c.render_frame(params, frame)
+                    step.wait()          # frame complete: the main thread copies it
+                    step.wait()
+        except Exception as e:           # surfaces in the main thread
+            errors.append(e)
+            start.abort(); step.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(n)]
+    for t in threads:
+        t.start()
+    try:
+        start.wait()
+        for _ in range(3):
+            step.wait()
+            got.append(frame.copy())
+            step.wait()
+    except threading.BrokenBarrierError:
+        pass
+    for t in threads:
+        t.join(timeout=60)
+    assert not errors, errors
+    for i in range(3):
+        assert_frames_equal(got[i], frames[i], f"threaded frame {i}")
+
+
 def test_page_locked_host_frame(abi):
     """luma_hip_host_alloc: the same pixels arrive in a page-locked frame as in a pageable one."""
     W, H = 128, 72
