@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="profiling aid: render only one band of this many bands on one GPU")
     ap.add_argument("--emulate-rank", type=int, default=0, help="which band --emulate-world renders")
+    ap.add_argument("--grid", action="store_true",
+                    help="LUMA_FLAG_GRID: closest-hit tests through the uniform grid (same frame, not the reference's linear scan)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: init the process group and run the gather collectives even with one rank")
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
@@ -147,7 +149,7 @@ def main():
     else:
         ctx.set_frame(WIDTH, HEIGHT, y0, y1)
     params = abi.make_params(WIDTH, HEIGHT, spp=SPP, bounces=BOUNCES, paths=PATHS, samples=SAMPLES,
-                             mode=wl["mode"], flags=wl["flags"], seed=SEED)
+                             mode=wl["mode"], flags=wl["flags"] | (abi.FLAG_GRID if a.grid else 0), seed=SEED)
     stream = torch.cuda.Stream(device=dev)          # a real (non-null) stream: kernels, gather and events share it
     torch.cuda.set_stream(stream)
     pipelined = use_dist and (stripe or HEIGHT % world == 0) and not rehearsal
@@ -223,7 +225,7 @@ def main():
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, not a measurement)" if rehearsal and world > 1 else ""),
-            "config": {"workload": wl["name"] + f", seed 0x{SEED:08X}"
+            "config": {"workload": wl["name"] + f", seed 0x{SEED:08X}" + (", uniform grid (LUMA_FLAG_GRID)" if a.grid else "")
                                    + (f", band {a.emulate_rank} of {a.emulate_world} only" if a.emulate_world else ""),
                        "parallelism": (f"{world} ranks, interleaved {stripe}-row stripes, RCCL gather to rank 0" if world > 1 and stripe
                                        else f"{world} scanline band(s), RCCL gather to rank 0")},

@@ -42,8 +42,12 @@ enum {
     LUMA_FLAG_ORIGIN_FROM_HIT = 2u, /* bounce rays start at the hit point + .001 normal (Renderer.cpp:221-222) instead of camera.pos (:303) */
     LUMA_FLAG_CLAMP_PACK      = 4u, /* clamp channels to [0,255] before packing (Renderer.cpp:44-55 does not) */
     LUMA_FLAG_NO_SHOW_DEPTH   = 8u, /* skip the in-focus x1.2 (Renderer.cpp:448-454) regardless of camera.show_depth */
-    LUMA_FLAG_PACK_RGBA8      = 16u /* target bytes R,G,B,255 (0xFFBBGGRR) instead of ::RGB's 0x00RRGGBB (Renderer.cpp:44-55);
-                                       same truncation and OR-combining, so combine with CLAMP_PACK for display use */
+    LUMA_FLAG_PACK_RGBA8      = 16u, /* target bytes R,G,B,255 (0xFFBBGGRR) instead of ::RGB's 0x00RRGGBB (Renderer.cpp:44-55);
+                                        same truncation and OR-combining, so combine with CLAMP_PACK for display use */
+    LUMA_FLAG_GRID            = 32u  /* closest-hit tests only against the spheres of the uniform-grid cells a ray crosses
+                                        instead of all of Renderer::spheres (Renderer.cpp:242); same tests, same winner,
+                                        same frame bit for bit, far fewer tests in large scenes.  luma_stats.sphere_tests
+                                        then counts the tests made.  Not the reference's scan: off by default */
 };
 
 typedef struct luma_ctx luma_ctx;

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("LUMA_HIP_LIB") or os.path.join(_PKG, "libluma_hip.so"
 
 OK, E_ARG, E_HIP, E_NOMEM, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5
 MODE_RAYTRACE, MODE_PATHTRACE = 0, 1
-FLAG_NOISE_OFF, FLAG_ORIGIN_FROM_HIT, FLAG_CLAMP_PACK, FLAG_NO_SHOW_DEPTH, FLAG_PACK_RGBA8 = 1, 2, 4, 8, 16
+FLAG_NOISE_OFF, FLAG_ORIGIN_FROM_HIT, FLAG_CLAMP_PACK, FLAG_NO_SHOW_DEPTH, FLAG_PACK_RGBA8, FLAG_GRID = 1, 2, 4, 8, 16, 32
 
 # every symbol include/luma_hip.h declares (checked by tests/test_abi_symbols.py)
 SYMBOLS = [

@@ -4,12 +4,14 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <new>
 #include <vector>
 
+#include "luma_grid.h"
 #include "luma_host.h"
 #include "luma_kernels.h"
 
@@ -17,7 +19,7 @@ namespace {
 
 thread_local char g_last_error[512] = "";
 
-constexpr size_t kCounterBytes = sizeof(unsigned long long) * luma::kCounterSlots * luma::kCounterStride;
+constexpr size_t kCounterBytes = sizeof(unsigned long long) * luma::kCounterSlots * luma::kCounterStride;   // per line: rays, grid tests, grid rays
 constexpr size_t kCounterAlloc = kCounterBytes + 64;   // + one line for the sphere-parallel kernel's tile counter
 
 int fail(int code, const char* what, const char* detail)
@@ -100,6 +102,15 @@ struct luma_ctx {
     unsigned long long* d_counters = nullptr;  // rays traced since luma_hip_create, in kCounterSlots partial sums
     unsigned long long* h_counters = nullptr;  // pinned
     unsigned long long rays_reported = 0;      // part of that total already handed out in a luma_stats
+    unsigned long long grid_tests_reported = 0, grid_rays_reported = 0;
+
+    // LUMA_FLAG_GRID: the spheres as given (the grid is built from them on first use) and the grid
+    std::vector<luma_sphere> host_spheres;
+    bool grid_stale = true;
+    luma::GridArgs grid{};
+    uint32_t* d_grid_cells = nullptr;
+    uint32_t* d_grid_items = nullptr;
+    uint32_t* d_grid_large = nullptr;
 
     size_t band_pixels() const { return static_cast<size_t>(rows) * width; }
 };
@@ -169,6 +180,7 @@ luma::RenderArgs make_args(const luma_ctx* ctx, const luma_params* p, uint32_t* 
     a.tile_counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_counters) + kCounterBytes);
     a.split = 1;
     a.split_scratch = nullptr;
+    a.grid = ctx->grid;
     return a;
 }
 
@@ -178,6 +190,39 @@ int refresh_records(luma_ctx* ctx, hipStream_t stream)
     LUMA_HIP_TRY(luma::launch_prepare_records(ctx->d_cx, ctx->d_cy, ctx->d_cz, ctx->d_rad, ctx->n_spheres,
                                               ctx->camera.pos, ctx->d_records, stream));
     ctx->records_stale = false;
+    return LUMA_OK;
+}
+
+// LUMA_FLAG_GRID: build the grid from the scene on first use and after every luma_hip_set_scene.
+int refresh_grid(luma_ctx* ctx)
+{
+    if (!ctx->grid_stale) { return LUMA_OK; }
+    luma::HostGrid g;
+    try {
+        luma::build_grid(ctx->host_spheres.data(), static_cast<uint32_t>(ctx->host_spheres.size()), g);
+    } catch (...) {
+        return fail(LUMA_E_NOMEM, "LUMA_FLAG_GRID", "host allocation failed while building the grid");
+    }
+    LUMA_HIP_TRY(hipDeviceSynchronize());                        // a launch may still walk the old grid
+    free_dev(ctx->d_grid_cells); free_dev(ctx->d_grid_items); free_dev(ctx->d_grid_large);
+    auto upload = [](uint32_t*& dst, const std::vector<uint32_t>& src) -> hipError_t {
+        const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(uint32_t);
+        hipError_t e = hipMalloc(&dst, bytes);
+        if (e == hipSuccess && !src.empty()) { e = hipMemcpy(dst, src.data(), src.size() * sizeof(uint32_t), hipMemcpyHostToDevice); }
+        return e;
+    };
+    LUMA_HIP_TRY(upload(ctx->d_grid_cells, g.cell_start));
+    LUMA_HIP_TRY(upload(ctx->d_grid_items, g.items));
+    LUMA_HIP_TRY(upload(ctx->d_grid_large, g.large));
+    luma::GridArgs& a = ctx->grid;
+    for (int i = 0; i < 3; i++) { a.dims[i] = g.dims[i]; a.org[i] = g.org[i]; }
+    a.h = g.h;
+    a.inv_h = 1.0f / g.h;
+    a.cell_start = ctx->d_grid_cells;
+    a.items = ctx->d_grid_items;
+    a.large = ctx->d_grid_large;
+    a.n_large = static_cast<uint32_t>(g.large.size());
+    ctx->grid_stale = false;
     return LUMA_OK;
 }
 
@@ -194,8 +239,10 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
 {
     if (int rc = order_after_previous(ctx, stream)) { return rc; }
     if (int rc = refresh_records(ctx, stream)) { return rc; }
+    const bool grid = (p->flags & LUMA_FLAG_GRID) != 0 && ctx->n_spheres > 0;
+    if (grid) { if (int rc = refresh_grid(ctx)) { return rc; } }
     luma::RenderArgs args = make_args(ctx, p, target_dev);
-    args.split = luma::choose_split(ctx->band_pixels(), p->spp, ctx->n_spheres);
+    args.split = luma::choose_split(ctx->band_pixels(), p->spp, ctx->n_spheres, grid);
     if (args.split > 1) {
         const size_t need = static_cast<size_t>(p->spp) * 3u * ctx->band_pixels() * sizeof(float);   // a slot per frame
         if (need > (size_t(2) << 30)) {
@@ -209,7 +256,7 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
         }
         args.split_scratch = ctx->d_split;
     }
-    if (luma::sphere_parallel_scene(ctx->n_spheres)) {
+    if (!grid && luma::sphere_parallel_scene(ctx->n_spheres)) {
         LUMA_HIP_TRY(hipMemsetAsync(args.tile_counter, 0, sizeof(uint32_t), stream));
     }
     // the events are only recorded for calls that report a luma_stats: each is a packet of its own
@@ -227,14 +274,22 @@ int collect_stats(luma_ctx* ctx, hipStream_t stream, luma_stats* stats)
 {
     LUMA_HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, kCounterBytes, hipMemcpyDeviceToHost, stream));
     LUMA_HIP_TRY(hipStreamSynchronize(stream));
-    unsigned long long total = 0;
-    for (uint32_t i = 0; i < luma::kCounterSlots; i++) { total += ctx->h_counters[i * luma::kCounterStride]; }
+    unsigned long long total = 0, grid_tests = 0, grid_rays = 0;
+    for (uint32_t i = 0; i < luma::kCounterSlots; i++) {
+        total += ctx->h_counters[i * luma::kCounterStride];
+        grid_tests += ctx->h_counters[i * luma::kCounterStride + 1];
+        grid_rays += ctx->h_counters[i * luma::kCounterStride + 2];
+    }
     float ms = 0.f;
     LUMA_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     stats->kernel_ms = ms;
     stats->rays = total - ctx->rays_reported;   // since the previous luma_stats
     ctx->rays_reported = total;
-    stats->sphere_tests = stats->rays * ctx->n_spheres;   // every ray scans every sphere (Renderer.cpp:242)
+    // a linear-scan ray tests every sphere (Renderer.cpp:242); rays of LUMA_FLAG_GRID launches count their own
+    const unsigned long long g_rays = grid_rays - ctx->grid_rays_reported, g_tests = grid_tests - ctx->grid_tests_reported;
+    ctx->grid_rays_reported = grid_rays;
+    ctx->grid_tests_reported = grid_tests;
+    stats->sphere_tests = (stats->rays - g_rays) * ctx->n_spheres + g_tests;
     return LUMA_OK;
 }
 
@@ -343,6 +398,7 @@ void luma_hip_destroy(luma_ctx* ctx)
     free_dev(ctx->d_cx); free_dev(ctx->d_cy); free_dev(ctx->d_cz); free_dev(ctx->d_rad);
     free_dev(ctx->d_mat0); free_dev(ctx->d_mat1); free_dev(ctx->d_records);
     free_dev(ctx->d_acc); free_dev(ctx->d_target); free_dev(ctx->d_counters); free_dev(ctx->d_split);
+    free_dev(ctx->d_grid_cells); free_dev(ctx->d_grid_items); free_dev(ctx->d_grid_large);
     if (ctx->h_counters) { (void)hipHostFree(ctx->h_counters); }
     if (ctx->ev_begin) { (void)hipEventDestroy(ctx->ev_begin); }
     if (ctx->ev_end) { (void)hipEventDestroy(ctx->ev_end); }
@@ -365,6 +421,10 @@ int luma_hip_set_scene(luma_ctx* ctx, const luma_sphere* spheres, uint32_t n)
     ctx->n_spheres = 0;
     ctx->have_scene = false;          // until every array below is in place
     ctx->records_stale = true;
+    ctx->grid_stale = true;
+    try { ctx->host_spheres.assign(spheres, spheres + n); } catch (...) {
+        return fail(LUMA_E_NOMEM, "luma_hip_set_scene", "host allocation failed");
+    }
     if (n == 0) { ctx->have_scene = true; return LUMA_OK; }   // empty scene: every ray misses (Renderer.cpp:276)
 
     // AoS (renderer.h:23-36) -> SoA geometry + packed material vectors

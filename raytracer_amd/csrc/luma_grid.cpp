@@ -1,0 +1,131 @@
+#include "luma_grid.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace luma {
+
+namespace {
+
+constexpr uint32_t kMaxDim = 256;             // cells per axis
+constexpr uint64_t kMaxCells = 4u << 20;      // 4M cells = 16 MB of offsets
+constexpr uint32_t kMaxSpan = 64;             // a sphere listed in more cells than this is "large"
+
+struct Box { float lo[3], hi[3]; };
+
+// The sphere's bounding box, widened by more than any rounding of the ray-sphere arithmetic can
+// move a reported hit point: a hit the reference's float test accepts lies within a few ulp of
+// the sphere, i.e. well inside this box.
+bool sphere_box(const luma_sphere& s, Box& b)
+{
+    const float c[3] = { s.cx, s.cy, s.cz };
+    const float r = std::fabs(s.radius);
+    if (!std::isfinite(r) || !std::isfinite(c[0]) || !std::isfinite(c[1]) || !std::isfinite(c[2])) { return false; }
+    const float reach = std::max({ std::fabs(c[0]), std::fabs(c[1]), std::fabs(c[2]) }) + r;
+    const float pad = 1e-4f * reach + 1e-30f;
+    for (int a = 0; a < 3; a++) { b.lo[a] = c[a] - r - pad; b.hi[a] = c[a] + r + pad; }
+    return std::isfinite(b.lo[0] + b.lo[1] + b.lo[2] + b.hi[0] + b.hi[1] + b.hi[2]);
+}
+
+}  // namespace
+
+void build_grid(const luma_sphere* spheres, uint32_t n, HostGrid& g)
+{
+    g = HostGrid{};
+    std::vector<Box> boxes(n);
+    std::vector<uint8_t> small(n, 0);
+    std::vector<float> radii;
+    radii.reserve(n);
+    for (uint32_t i = 0; i < n; i++) {
+        if (sphere_box(spheres[i], boxes[i])) { small[i] = 1; radii.push_back(std::fabs(spheres[i].radius)); }
+    }
+    float r_med = 0.f;
+    if (!radii.empty()) {
+        std::nth_element(radii.begin(), radii.begin() + radii.size() / 2, radii.end());
+        r_med = radii[radii.size() / 2];
+    }
+    // a sphere much larger than the typical one (the ground) would sit in thousands of cells
+    uint32_t n_small = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (small[i] && r_med > 0.f && std::fabs(spheres[i].radius) > 8.f * r_med) { small[i] = 0; }
+        n_small += small[i];
+    }
+
+    float lo[3] = { 0.f, 0.f, 0.f }, hi[3] = { 0.f, 0.f, 0.f };
+    bool first = true;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!small[i]) { continue; }
+        for (int a = 0; a < 3; a++) {
+            lo[a] = first ? boxes[i].lo[a] : std::min(lo[a], boxes[i].lo[a]);
+            hi[a] = first ? boxes[i].hi[a] : std::max(hi[a], boxes[i].hi[a]);
+        }
+        first = false;
+    }
+    if (n_small) {
+        // about two cells per sphere, cells no smaller than the median radius
+        double ext[3], vol = 1.0;
+        for (int a = 0; a < 3; a++) { ext[a] = std::max(double(hi[a]) - lo[a], 1e-20); vol *= ext[a]; }
+        // (measured at 4096 and 65536 spheres: 1 / 2 / 4 / 8 cells per sphere -> 3.05 / 2.93 / 2.97 / 3.16 and
+        //  3.92 / 3.64 / 3.53 / 3.44 ms per 1080p x 2 spp call)
+        double h = std::max(std::cbrt(vol / (2.0 * n_small)), double(r_med));
+        const double longest = std::max({ ext[0], ext[1], ext[2] });
+        h = std::max(h, longest / kMaxDim);
+        for (;;) {
+            uint64_t cells = 1;
+            for (int a = 0; a < 3; a++) {
+                g.dims[a] = static_cast<uint32_t>(std::min<double>(kMaxDim, std::max(1.0, std::ceil(ext[a] / h))));
+                cells *= g.dims[a];
+            }
+            if (cells <= kMaxCells) { break; }
+            h *= 1.26;
+        }
+        g.h = static_cast<float>(h);
+        // one cell of slack around the boxes so that no sphere touches the outer faces
+        for (int a = 0; a < 3; a++) {
+            g.org[a] = lo[a] - g.h;
+            g.dims[a] = std::min(kMaxDim + 2u, g.dims[a] + 2u);
+        }
+    }
+
+    const uint32_t dx = g.dims[0], dy = g.dims[1], dz = g.dims[2];
+    const size_t n_cells = static_cast<size_t>(dx) * dy * dz;
+    auto cell_range = [&](const Box& b, uint32_t c0[3], uint32_t c1[3]) {
+        uint64_t span = 1;
+        for (int a = 0; a < 3; a++) {
+            const float slack = 1e-3f * g.h;
+            const double f0 = std::floor((double(b.lo[a]) - slack - g.org[a]) / g.h);
+            const double f1 = std::floor((double(b.hi[a]) + slack - g.org[a]) / g.h);
+            c0[a] = static_cast<uint32_t>(std::min<double>(g.dims[a] - 1, std::max(0.0, f0)));
+            c1[a] = static_cast<uint32_t>(std::min<double>(g.dims[a] - 1, std::max(0.0, f1)));
+            span *= c1[a] - c0[a] + 1;
+        }
+        return span;
+    };
+    std::vector<uint32_t> count(n_cells + 1, 0);
+    for (uint32_t i = 0; i < n; i++) {
+        if (!small[i]) { continue; }
+        uint32_t c0[3], c1[3];
+        if (cell_range(boxes[i], c0, c1) > kMaxSpan) { small[i] = 0; continue; }
+        for (uint32_t z = c0[2]; z <= c1[2]; z++) {
+            for (uint32_t y = c0[1]; y <= c1[1]; y++) {
+                for (uint32_t x = c0[0]; x <= c1[0]; x++) { count[(static_cast<size_t>(z) * dy + y) * dx + x + 1]++; }
+            }
+        }
+    }
+    for (size_t c = 0; c < n_cells; c++) { count[c + 1] += count[c]; }
+    g.cell_start = count;
+    g.items.assign(count[n_cells], 0);
+    std::vector<uint32_t> fill(count.begin(), count.end() - 1);
+    for (uint32_t i = 0; i < n; i++) {                     // ascending i => ascending inside every cell
+        if (!small[i]) { g.large.push_back(i); continue; }
+        uint32_t c0[3], c1[3];
+        cell_range(boxes[i], c0, c1);
+        for (uint32_t z = c0[2]; z <= c1[2]; z++) {
+            for (uint32_t y = c0[1]; y <= c1[1]; y++) {
+                for (uint32_t x = c0[0]; x <= c1[0]; x++) { g.items[fill[(static_cast<size_t>(z) * dy + y) * dx + x]++] = i; }
+            }
+        }
+    }
+}
+
+}  // namespace luma

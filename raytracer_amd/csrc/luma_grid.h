@@ -1,0 +1,27 @@
+// luma_grid.h -- uniform grid over the scene's spheres (host side).  An optional accelerator for
+// the closest-hit scan (LUMA_FLAG_GRID): it only decides WHICH spheres a ray is tested against;
+// the test itself and the choice among hits are the reference's (Renderer.cpp:242-285), so the
+// frame is the linear scan's, bit for bit.  No counterpart in the reference.
+#pragma once
+
+#include <stdint.h>
+
+#include <vector>
+
+#include "luma_hip.h"
+
+namespace luma {
+
+struct HostGrid {
+    uint32_t dims[3] = { 1, 1, 1 };
+    float org[3] = { 0.f, 0.f, 0.f };       // minimum corner
+    float h = 1.f;                          // cell edge
+    std::vector<uint32_t> cell_start;       // dims.x * dims.y * dims.z + 1 offsets into items
+    std::vector<uint32_t> items;            // sphere indices, ascending inside a cell
+    std::vector<uint32_t> large;            // spheres tested against every ray (ground plane, non-finite, ...)
+};
+
+// Never fails for finite n; spheres the grid cannot hold go to `large`.
+void build_grid(const luma_sphere* spheres, uint32_t n, HostGrid& out);
+
+}  // namespace luma

@@ -13,6 +13,7 @@ enum : uint32_t {
     FLAG_CLAMP_PACK      = 4u,
     FLAG_NO_SHOW_DEPTH   = 8u,
     FLAG_PACK_RGBA8      = 16u,
+    FLAG_GRID            = 32u,
 };
 enum : uint32_t { MODE_RAYTRACE = 0, MODE_PATHTRACE = 1 };
 
@@ -27,6 +28,17 @@ static constexpr uint32_t kSphereParallelMin = 320;   // measured crossover (too
 // The ray counter is kCounterSlots 64-bit slots, one per 64-byte line (stride in u64).
 static constexpr uint32_t kCounterSlots = 256;
 static constexpr uint32_t kCounterStride = 8;
+
+// Uniform grid over the spheres (luma_grid.h), used by the ray-per-lane kernel under FLAG_GRID.
+struct GridArgs {
+    uint32_t dims[3];
+    float    org[3];
+    float    h, inv_h;
+    const uint32_t* cell_start;    // dims.x * dims.y * dims.z + 1
+    const uint32_t* items;         // sphere indices per cell, ascending
+    const uint32_t* large;         // spheres tested against every ray
+    uint32_t n_large;
+};
 
 // Passed by value as the kernel argument (lands in SGPRs / the kernarg segment).
 struct RenderArgs {
@@ -59,12 +71,13 @@ struct RenderArgs {
     uint32_t  split;
     float*    split_scratch;
     uint32_t* tile_counter;        // sphere-parallel kernel: next wave tile, zeroed before every launch
-    unsigned long long* counters;  // kCounterSlots x kCounterStride: rays traced, summed by the host
+    unsigned long long* counters;  // kCounterSlots x kCounterStride: [0] rays traced, [1] sphere tests; summed by the host
+    GridArgs  grid;                // only read under FLAG_GRID
 };
 
 size_t     scene_lds_bytes(uint32_t n_spheres);
 bool       sphere_parallel_scene(uint32_t n_spheres);
-uint32_t   choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres);
+uint32_t   choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid);
 hipError_t launch_prepare_records(const float* cx, const float* cy, const float* cz, const float* rad,
                                   uint32_t n, const float pos[3], float4* records, hipStream_t stream);
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);

@@ -244,6 +244,105 @@ LUMA_DEV Hit finish_hit(const float4* __restrict__ rec_gen, int idx, f3 origin, 
     return h;
 }
 
+// Closest hit through the uniform grid (FLAG_GRID): the spheres of the cells the ray crosses, in
+// the order it crosses them, plus the `large` list.  Each sphere gets the reference's test
+// (:244-258) and the winner is the smallest t, the lowest index among equal t (:266) -- a rule
+// that does not depend on the order of the tests, so the result is the linear scan's.  The walk
+// stops once the best hit lies before the exit of the current cell by a clear margin; the cell
+// lists are built from boxes padded by more than the arithmetic can displace a hit (luma_grid.cpp).
+template <bool CAM_ORIGIN>
+LUMA_DEV int scan_grid(const GridArgs& G, const float4* __restrict__ rec_cam, const float4* __restrict__ rec_gen,
+                       f3 origin, f3 dir, float& t_out, uint32_t& n_tests)
+{
+    const float a = dot3(dir, dir);                              // :246
+    float best_t = FLT_MAX;
+    int best = -1;
+    auto test = [&](uint32_t i) {
+        float b, c;
+        if (CAM_ORIGIN) {
+            const float4 s = rec_cam[i];
+            b = dot3(mk3(s.x, s.y, s.z), dir);
+            c = s.w;
+        } else {
+            const float4 s = rec_gen[i];
+            const f3 diff = sub3(origin, mk3(s.x, s.y, s.z));    // :244
+            b = dot3(diff, dir);
+            c = fma_(-s.w, s.w, dot3(diff, diff));               // :248
+        }
+        const float d = fma_(b, b, -(a * c));
+        n_tests++;
+        if (d > 0.0f && b < 0.0f) {                              // :253
+            const float t = (-b - sqrt_rn(d)) / a;               // :255
+            if (t > 0.0f && (t < best_t || (t == best_t && (int)i < best))) { best_t = t; best = (int)i; }   // :258, :266
+        }
+    };
+
+    for (uint32_t j = 0; j < G.n_large; j++) { test(G.large[j]); }
+
+    // the part of the ray inside the grid's box: [t0, t1]  (per-axis scalars: no indexed registers)
+    float t0 = 0.0f, t1 = FLT_MAX;
+    bool inside = true;
+    auto clip = [&](float o, float d, float org, uint32_t dim, float& inv) {
+        const float lo = org, hi = org + (float)dim * G.h;
+        if (d != 0.0f) {
+            inv = 1.0f / d;
+            const float ta = (lo - o) * inv, tb = (hi - o) * inv;
+            t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+            t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+        } else {
+            inv = 0.0f;
+            inside = inside && (o >= lo && o <= hi);
+        }
+    };
+    float ix, iy, iz;
+    clip(origin.x, dir.x, G.org[0], G.dims[0], ix);
+    clip(origin.y, dir.y, G.org[1], G.dims[1], iy);
+    clip(origin.z, dir.z, G.org[2], G.dims[2], iz);
+    if (inside && t0 <= t1 && a > 0.0f) {
+        float t_cell = FLT_MAX;                                  // time to cross one cell along the fastest axis
+        auto enter = [&](float o, float d, float inv, float org, uint32_t dim, int& cell, float& t_next) {
+            const float p = fma_(d, t0, o);
+            cell = min(max((int)__builtin_floorf((p - org) * G.inv_h), 0), (int)dim - 1);
+            if (d != 0.0f) {
+                t_next = (org + (float)(cell + (d > 0.0f ? 1 : 0)) * G.h - o) * inv;
+                t_cell = __builtin_fminf(t_cell, G.h * __builtin_fabsf(inv));
+            } else {
+                t_next = FLT_MAX;
+            }
+        };
+        int cx, cy, cz;
+        float tx, ty, tz;
+        enter(origin.x, dir.x, ix, G.org[0], G.dims[0], cx, tx);
+        enter(origin.y, dir.y, iy, G.org[1], G.dims[1], cy, ty);
+        enter(origin.z, dir.z, iz, G.org[2], G.dims[2], cz, tz);
+        const float margin = 1e-3f * t_cell;
+        const uint32_t most = G.dims[0] + G.dims[1] + G.dims[2] + 3u;    // a straight line crosses no more cells
+        for (uint32_t hop = 0; hop < most; hop++) {
+            const size_t id = ((size_t)cz * G.dims[1] + (size_t)cy) * G.dims[0] + (size_t)cx;
+            const uint32_t k1 = G.cell_start[id + 1];
+            for (uint32_t k = G.cell_start[id]; k < k1; k++) { test(G.items[k]); }
+            const float t_exit = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+            if (best_t < t_exit - margin || t_exit > t1 + margin) { break; }
+            // cross the nearest face (when two are due at once, one per hop)
+            if (tx <= ty && tx <= tz) {
+                cx += dir.x > 0.0f ? 1 : -1;
+                if (cx < 0 || cx >= (int)G.dims[0]) { break; }
+                tx = (G.org[0] + (float)(cx + (dir.x > 0.0f ? 1 : 0)) * G.h - origin.x) * ix;
+            } else if (ty <= tz) {
+                cy += dir.y > 0.0f ? 1 : -1;
+                if (cy < 0 || cy >= (int)G.dims[1]) { break; }
+                ty = (G.org[1] + (float)(cy + (dir.y > 0.0f ? 1 : 0)) * G.h - origin.y) * iy;
+            } else {
+                cz += dir.z > 0.0f ? 1 : -1;
+                if (cz < 0 || cz >= (int)G.dims[2]) { break; }
+                tz = (G.org[2] + (float)(cz + (dir.z > 0.0f ? 1 : 0)) * G.h - origin.z) * iz;
+            }
+        }
+    }
+    t_out = best_t;
+    return best;
+}
+
 // ::RGB's shift-and-OR (Renderer.cpp:48-52), or the byte order R,G,B,255 for PACK_RGBA8.
 LUMA_DEV uint32_t pack_pixel(int r, int g, int b, uint32_t flags)
 {
@@ -301,7 +400,7 @@ enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 // frame order, so the float sum is still the reference's ((acc + f0) + f1) + ...
 // (Renderer.cpp:457-458), bit for bit.  Which lane renders which frame is settled at run time
 // (see `claim` below).
-template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT>
+template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT, bool GRID>
 __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 {
     // [0,n): camera-origin records; [n,2n): general records; then mat0[n] (float4), mat1[n] (float2)
@@ -344,7 +443,17 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
     const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
     const uint32_t slots = 2u + A.paths;
     const bool pathtrace = A.mode == MODE_PATHTRACE;
-    uint32_t nrays = 0;
+    uint32_t nrays = 0, ntests = 0;                              // ntests: counted under GRID only (else rays * n)
+
+    // Renderer::trace_ray (:234-287): linear scan, or the same tests through the grid
+    auto closest_cam = [&](f3 o, f3 d, float& t) {
+        if (GRID) { return scan_grid<true>(A.grid, rec_cam, rec_gen, o, d, t, ntests); }
+        return scan_spheres<true, (SCENE == SCENE_GLOBAL)>(rec_cam, n, o, d, t);
+    };
+    auto closest_gen = [&](f3 o, f3 d, float& t) {
+        if (GRID) { return scan_grid<false>(A.grid, rec_cam, rec_gen, o, d, t, ntests); }
+        return scan_spheres<false, (SCENE == SCENE_GLOBAL)>(rec_gen, n, o, d, t);
+    };
 
     // DOF pre-pass, :416-432.  Noise free, so it is the same for every frame of the call; with
     // SPLIT > 1 lane 0 of the pixel traces it and hands blur and gain to the others through LDS.
@@ -361,7 +470,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
     if (live) { dir0 = camera_ray(A, x, y); }                    // camera.rays[index], :413
     if (live && k == 0) {
         float t0;
-        const int h0 = scan_spheres<true, (SCENE == SCENE_GLOBAL)>(rec_cam, n, campos, dir0, t0);
+        const int h0 = closest_cam(campos, dir0, t0);
         nrays++;
         const float depth = (h0 >= 0) ? t0 : FLT_MAX;            // :419-423
         const float dd = depth - A.focus_depth;                  // :425
@@ -408,8 +517,8 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
 
             float t;
             int idx;
-            if (FROM_HIT && bounce > 0) { idx = scan_spheres<false, (SCENE == SCENE_GLOBAL)>(rec_gen, n, origin, dn, t); }
-            else                        { idx = scan_spheres<true, (SCENE == SCENE_GLOBAL)>(rec_cam, n, origin, dn, t); }   // :304
+            if (FROM_HIT && bounce > 0) { idx = closest_gen(origin, dn, t); }
+            else                        { idx = closest_cam(origin, dn, t); }   // :304
             nrays++;
 
             bool path_ends;
@@ -434,7 +543,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
                                 if (dot3(d, hit.normal) < 0.0f) { d = neg3(d); }   // :197-200
                                 const f3 nd = add3(hit.normal, d);     // :202
                                 float tc;
-                                const int ci = scan_spheres<false, (SCENE == SCENE_GLOBAL)>(rec_gen, n, hit.pos, nd, tc);   // :204
+                                const int ci = closest_gen(hit.pos, nd, tc);   // :204
                                 nrays++;
                                 if (ci >= 0) {                   // :206-209
                                     const float4 cm = mat0[ci];
@@ -522,6 +631,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
     }
 
     wave_add_u64(A.counters, nrays);
+    if (GRID) { wave_add_u64(A.counters + 1, ntests); wave_add_u64(A.counters + 2, nrays); }   // tests, and rays of grid launches
 }
 
 // ---------------------------------------------------------------------------------
@@ -872,9 +982,9 @@ bool sphere_parallel_scene(uint32_t n_spheres)
         && (size_t)((n_spheres + 63u) & ~63u) * 2u * sizeof(float4) <= kMaxSceneLdsBytes;
 }
 
-uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres)
+uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid)
 {
-    if (sphere_parallel_scene(n_spheres)) { return 1; }
+    if (!grid && sphere_parallel_scene(n_spheres)) { return 1; }
     // measured on MI355X, bands of the 1080p x 64 spp frame (kernel ms for 1 / 2 / 4 lanes per pixel):
     // 2.07M px 2.09 / 2.13 / 2.32, 1.04M px 1.17 / 1.11 / 1.17, 518k px 0.66 / 0.61 / 0.60,
     // 259k px 0.50 / 0.36 / 0.33
@@ -914,7 +1024,8 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     kernel_t k;
     size_t lds;
     int waves, split = 1;
-    const bool sphere_parallel = sphere_parallel_scene(n);
+    const bool use_grid = (args.flags & FLAG_GRID) != 0 && n > 0;
+    const bool sphere_parallel = !use_grid && sphere_parallel_scene(n);
     if (sphere_parallel) {
         // The kernel needs ~90 VGPRs, so a SIMD holds 5 waves: five 4-wave workgroups per CU
         // (20 waves) fit while each needs <= 32 KiB of the 160 KiB LDS; beyond that one 16-wave
@@ -935,15 +1046,22 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         lds = scene == SCENE_LDS_ALL ? all_bytes : 0;
         waves = 4;
         split = args.split;
-#define LUMA_K(S, P) { { render_kernel<kTileW, 4, S, false, false, P>, render_kernel<kTileW, 4, S, false, true, P> }, \
-                       { render_kernel<kTileW, 4, S, true, false, P>,  render_kernel<kTileW, 4, S, true, true, P> } }
+#define LUMA_K(S, P, G) { { render_kernel<kTileW, 4, S, false, false, P, G>, render_kernel<kTileW, 4, S, false, true, P, G> }, \
+                          { render_kernel<kTileW, 4, S, true, false, P, G>,  render_kernel<kTileW, 4, S, true, true, P, G> } }
         static const kernel_t table[3][2][2][2] = {
-            { LUMA_K(SCENE_GLOBAL, 1), LUMA_K(SCENE_LDS_ALL, 1) },
-            { LUMA_K(SCENE_GLOBAL, 2), LUMA_K(SCENE_LDS_ALL, 2) },
-            { LUMA_K(SCENE_GLOBAL, 4), LUMA_K(SCENE_LDS_ALL, 4) },
+            { LUMA_K(SCENE_GLOBAL, 1, false), LUMA_K(SCENE_LDS_ALL, 1, false) },
+            { LUMA_K(SCENE_GLOBAL, 2, false), LUMA_K(SCENE_LDS_ALL, 2, false) },
+            { LUMA_K(SCENE_GLOBAL, 4, false), LUMA_K(SCENE_LDS_ALL, 4, false) },
+        };
+        static const kernel_t grid_table[3][2][2] = {
+            LUMA_K(SCENE_GLOBAL, 1, true), LUMA_K(SCENE_GLOBAL, 2, true), LUMA_K(SCENE_GLOBAL, 4, true),
         };
 #undef LUMA_K
         k = table[split == 4 ? 2 : split == 2 ? 1 : 0][scene == SCENE_LDS_ALL][noise][from_hit];
+        if (use_grid) {                                          // records and materials stay in global memory
+            lds = 0;
+            k = grid_table[split == 4 ? 2 : split == 2 ? 1 : 0][noise][from_hit];
+        }
     }
     const int wpk = waves / split;                               // waves that tile pixels (the rest split frames)
     const int wgx = wg_waves_x(wpk), wgy = wpk / wgx;

@@ -121,3 +121,14 @@ def test_random_scene_matches_oracle(abi, oracle, c):
             assert np.array_equal(acc.view(np.uint32), ref.accum.view(np.uint32)), f"{c['id']} call {call}: accumulators"
         # the kernels trace the DOF ray once per call, the reference once per frame
         assert st.sphere_tests == st.rays * c["n"]
+
+        # the same calls with the uniform grid choosing the spheres to test (LUMA_FLAG_GRID)
+        ctx.reset()
+        ref = oracle.Renderer(o_scene, o_cam, W, H)
+        for call in range(c["calls"]):
+            got, gst = ctx.render(abi.make_params(W, H, **dict(kw, flags=kw["flags"] | abi.FLAG_GRID)))
+            ref.render(oracle.make_params(W, H, **kw))
+            diff = int((got != ref.target).sum())
+            assert diff == 0, f"{c['id']} grid, call {call}: {diff} of {W * H} pixels differ"
+            assert np.array_equal(ctx.read_accum().view(np.uint32), ref.accum.view(np.uint32)), f"{c['id']} grid: accumulators"
+        assert gst.rays == st.rays          # (a sphere listed in several cells may be tested more than once)

@@ -302,6 +302,30 @@ def test_synthetic_scene(abi, oracle, n, W, H, spp, flags, paths):
     assert st.sphere_tests == st.rays * n
 
 
+@pytest.mark.parametrize("n,W,H,spp,flags,posed", [
+    (5, 160, 90, 3, 0, False), (2, 64, 36, 2, 0, False), (64, 96, 54, 2, 2, False), (300, 96, 54, 2, 0, True),
+    (1000, 64, 36, 2, 1, False), (4096, 96, 54, 1, 0, False), (4096, 48, 27, 2, 2, True), (20000, 64, 36, 1, 0, False),
+])
+def test_grid_gives_the_linear_scan_frame(abi, oracle, n, W, H, spp, flags, posed):
+    """LUMA_FLAG_GRID: rays are tested only against the spheres of the grid cells they cross (plus
+    the few spheres too large for the grid); frame and accumulators equal the oracle's linear scan
+    bit for bit, with a fraction of the sphere tests."""
+    kw = dict(spp=spp, bounces=5, paths=1, samples=1, mode=1, seed=SEED)
+    scene = abi.default_scene() if n == 5 else abi.synthetic_scene(n)
+    oscene = oracle.default_scene() if n == 5 else oracle.synthetic_scene(n)
+    if posed:      # in the middle of the synthetic cloud, looking sideways
+        cam, ocam = abi.camera_from_pose(W, H, (5.0, -4.0, -40.0), 0.3, 1.2), oracle.camera_pose(W, H, (5.0, -4.0, -40.0), 0.3, 1.2)
+    else:
+        cam, ocam = abi.default_camera(W, H), oracle.camera(W, H)
+    got, acc, st = hip_render(abi, scene, cam, W, H, flags=flags | abi.FLAG_GRID, **kw)
+    want, wacc, ost = oracle.render(oscene, ocam, oracle.make_params(W, H, flags=flags, **kw))
+    assert_frames_equal(got, want, f"grid n={n}")
+    assert np.array_equal(acc.view(np.uint32), wacc.view(np.uint32))
+    assert st.rays == ost.rays - (spp - 1) * W * H
+    if n >= 1000:
+        assert st.sphere_tests * 10 < st.rays * n, "the grid should skip most of a large scene"
+
+
 def test_scene_generators_match_oracle(abi, oracle):
     a, o = abi.synthetic_scene(1000), oracle.synthetic_scene(1000)
     assert bytes(a) == bytes(o)
