@@ -326,6 +326,46 @@ def test_grid_gives_the_linear_scan_frame(abi, oracle, n, W, H, spp, flags, pose
         assert st.sphere_tests * 10 < st.rays * n, "the grid should skip most of a large scene"
 
 
+@pytest.mark.parametrize("kind", ["cluster_and_outliers", "line", "coincident", "shells", "flat"])
+def test_grid_on_awkward_distributions(abi, oracle, kind):
+    """Scenes a uniform grid handles badly (everything in one cell, a line of cells, hundreds of
+    identical or concentric spheres, a plane): still the linear scan's frame."""
+    rng = np.random.default_rng({"cluster_and_outliers": 1, "line": 2, "coincident": 3, "shells": 4, "flat": 5}[kind])
+    n = 600
+    pos = np.zeros((n, 3), np.float32)
+    rad = np.full(n, 0.3, np.float32)
+    if kind == "cluster_and_outliers":
+        pos[:] = rng.normal([0, 0, -12], 0.8, size=(n, 3))
+        pos[:8] = rng.uniform(-4000, 4000, size=(8, 3))
+    elif kind == "line":
+        pos[:, 2] = np.linspace(-4, -300, n)
+        pos[:, 0] = 0.01 * np.arange(n)
+    elif kind == "coincident":
+        pos[:] = [0.5, 0.2, -9]
+        pos[300:] = [-1.5, 0.1, -7]
+        rad[:] = 1.0
+    elif kind == "shells":
+        pos[:] = [0, 0, -15]
+        rad[:] = np.linspace(0.05, 6.0, n)
+    else:
+        pos[:, 0] = rng.uniform(-30, 30, n); pos[:, 2] = rng.uniform(-80, -5, n); pos[:, 1] = 1.5
+    a_scene, o_scene = (abi.Sphere * n)(), (oracle.Sphere * n)()
+    for i in range(n):
+        d = [float(v) for v in rng.uniform(0.1, 1, 3)]
+        a_scene[i] = abi.Sphere(float(pos[i, 0]), float(pos[i, 1]), float(pos[i, 2]), float(rad[i]), d[0], d[1], d[2], 1.0, [.001, .1, .4][i % 3], 0.3)
+        o = o_scene[i]
+        o.pos[:] = [float(v) for v in pos[i]]; o.radius = float(rad[i]); o.diffuse[:] = d
+        o.albedo, o.metallic, o.roughness = 1.0, [.001, .1, .4][i % 3], 0.3
+    assert bytes(a_scene) == bytes(o_scene)
+    W, H = 80, 45
+    for flags in (1, 0, 2):
+        kw = dict(spp=2, bounces=4, paths=1, samples=1, mode=1, seed=SEED)
+        got, acc, st = hip_render(abi, a_scene, abi.default_camera(W, H), W, H, flags=flags | abi.FLAG_GRID, **kw)
+        want, wacc, _ = oracle.render(o_scene, oracle.camera(W, H), oracle.make_params(W, H, flags=flags, **kw))
+        assert_frames_equal(got, want, f"grid, {kind}, flags={flags}")
+        assert np.array_equal(acc.view(np.uint32), wacc.view(np.uint32))
+
+
 def test_scene_generators_match_oracle(abi, oracle):
     a, o = abi.synthetic_scene(1000), oracle.synthetic_scene(1000)
     assert bytes(a) == bytes(o)
