@@ -225,6 +225,19 @@ int luma_scene_default(luma_sphere* out);
  * the counter RNG.  No counterpart in the reference. */
 int luma_scene_synthetic(luma_sphere* out, uint32_t n, uint64_t seed);
 
+/* Host-only view of the uniform grid LUMA_FLAG_GRID builds for a scene (no GPU work; for tests and
+ * tuning).  Call with the three arrays NULL to get the sizes, then again with
+ * cell_start[dims[0]*dims[1]*dims[2] + 1], items[n_items] and large[n_large].  Cell (x,y,z) is entry
+ * (z*dims[1] + y)*dims[0] + x and spans org + (x,y,z)*cell .. org + (x+1,y+1,z+1)*cell. */
+typedef struct {
+    uint32_t dims[3];
+    float    org[3];
+    float    cell;
+    uint32_t n_items, n_large;
+} luma_grid_info;
+int luma_grid_describe(const luma_sphere* spheres, uint32_t n, luma_grid_info* info,
+                       uint32_t* cell_start, uint32_t* items, uint32_t* large);
+
 /* ---- diagnostics --------------------------------------------------------------- */
 const char* luma_hip_strerror(int code);
 const char* luma_hip_last_error(void);   /* thread-local text of the last failure */

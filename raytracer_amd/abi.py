@@ -26,7 +26,7 @@ SYMBOLS = [
     "luma_hip_render_frame", "luma_hip_device_count", "luma_hip_group_create", "luma_hip_group_destroy",
     "luma_hip_group_size", "luma_hip_group_context", "luma_hip_group_set_scene", "luma_hip_group_set_camera",
     "luma_hip_group_set_frame", "luma_hip_group_reset", "luma_hip_group_render", "luma_hip_group_read_accum",
-    "luma_hip_host_alloc", "luma_hip_host_free",
+    "luma_hip_host_alloc", "luma_hip_host_free", "luma_grid_describe",
 ]
 
 
@@ -45,6 +45,11 @@ class Params(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32),
                 ("bounces", C.c_uint32), ("paths", C.c_uint32), ("mode", C.c_uint32),
                 ("spp", C.c_uint32), ("flags", C.c_uint32), ("seed", C.c_uint64)]
+
+
+class GridInfo(C.Structure):
+    _fields_ = [("dims", C.c_uint32 * 3), ("org", C.c_float * 3), ("cell", C.c_float),
+                ("n_items", C.c_uint32), ("n_large", C.c_uint32)]
 
 
 class Stats(C.Structure):
@@ -106,6 +111,7 @@ def lib():
         "luma_hip_group_read_accum": (C.c_int, [ctx, f32p]),
         "luma_hip_host_alloc": (C.c_int, [ctxp, C.c_size_t]),
         "luma_hip_host_free": (None, [C.c_void_p]),
+        "luma_grid_describe": (C.c_int, [C.POINTER(Sphere), C.c_uint32, C.POINTER(GridInfo), u32p, u32p, u32p]),
         "luma_hip_strerror": (C.c_char_p, [C.c_int]),
         "luma_hip_last_error": (C.c_char_p, []),
         "luma_hip_abi_version": (C.c_int, []),
@@ -182,6 +188,20 @@ class HostFrame:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def describe_grid(spheres):
+    """luma_grid_describe: (GridInfo, cell_start, items, large) as numpy arrays."""
+    n = len(spheres)
+    info = GridInfo()
+    check(lib().luma_grid_describe(spheres if n else None, n, C.byref(info), None, None, None), "luma_grid_describe")
+    cells = int(info.dims[0]) * int(info.dims[1]) * int(info.dims[2])
+    cell_start = np.zeros(cells + 1, dtype=np.uint32)
+    items = np.zeros(max(info.n_items, 1), dtype=np.uint32)
+    large = np.zeros(max(info.n_large, 1), dtype=np.uint32)
+    check(lib().luma_grid_describe(spheres if n else None, n, C.byref(info), _u32p(cell_start), _u32p(items), _u32p(large)),
+          "luma_grid_describe")
+    return info, cell_start, items[:info.n_items], large[:info.n_large]
 
 
 def device_count():

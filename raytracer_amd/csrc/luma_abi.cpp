@@ -852,6 +852,24 @@ int luma_camera_from_pose(float fov_deg, float nearclip, float farclip, uint32_t
     return LUMA_OK;
 }
 
+int luma_grid_describe(const luma_sphere* spheres, uint32_t n, luma_grid_info* info,
+                       uint32_t* cell_start, uint32_t* items, uint32_t* large)
+{
+    if (!info || (n > 0 && !spheres)) { return fail(LUMA_E_ARG, "luma_grid_describe", "null argument"); }
+    luma::HostGrid g;
+    try { luma::build_grid(spheres, n, g); } catch (...) {
+        return fail(LUMA_E_NOMEM, "luma_grid_describe", "host allocation failed");
+    }
+    for (int i = 0; i < 3; i++) { info->dims[i] = g.dims[i]; info->org[i] = g.org[i]; }
+    info->cell = g.h;
+    info->n_items = static_cast<uint32_t>(g.items.size());
+    info->n_large = static_cast<uint32_t>(g.large.size());
+    if (cell_start) { std::copy(g.cell_start.begin(), g.cell_start.end(), cell_start); }
+    if (items) { std::copy(g.items.begin(), g.items.end(), items); }
+    if (large) { std::copy(g.large.begin(), g.large.end(), large); }
+    return LUMA_OK;
+}
+
 int luma_scene_default(luma_sphere* out)
 {
     if (!out) { return fail(LUMA_E_ARG, "luma_scene_default", "null argument"); }
