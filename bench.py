@@ -93,8 +93,8 @@ def cpu_baseline(seconds_target=10.0, threads_all=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config3")
     ap.add_argument("--emulate-world", type=int, default=0,
