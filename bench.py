@@ -227,7 +227,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (gloo rehearsal, not a measurement)" if rehearsal and world > 1 else ""),
             "config": {"workload": wl["name"] + f", seed 0x{SEED:08X}" + (", uniform grid (LUMA_FLAG_GRID)" if a.grid else "")
                                    + (f", band {a.emulate_rank} of {a.emulate_world} only" if a.emulate_world else ""),
-                       "parallelism": (f"{world} ranks, interleaved {stripe}-row stripes, RCCL gather to rank 0" if world > 1 and stripe
+                       "parallelism": ("one GPU, whole frame" if world == 1 and not a.emulate_world
+                                       else f"{world} ranks, interleaved {stripe}-row stripes, RCCL gather to rank 0" if world > 1 and stripe
                                        else f"{world} scanline band(s), RCCL gather to rank 0")},
             "frame_ms": ms_per_step,
             "msamples_per_s": WIDTH * (HEIGHT // (a.emulate_world or 1)) * SPP * a.steps / dt / 1e6,
