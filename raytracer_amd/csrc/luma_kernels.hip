@@ -400,8 +400,10 @@ enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 // frame order, so the float sum is still the reference's ((acc + f0) + f1) + ...
 // (Renderer.cpp:457-458), bit for bit.  Which lane renders which frame is settled at run time
 // (see `claim` below).
+// (GRID: the walk waits on dependent loads, so six waves per SIMD with ~40 B of spills beat four
+//  without: 2.93 -> 2.15 ms at 4096 spheres; five: 2.42, seven: 2.12 / 3.05 at 65536, eight: 2.60)
 template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT, bool GRID>
-__global__ __launch_bounds__(WAVES * 64) void render_kernel(const RenderArgs A)
+__global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const RenderArgs A)
 {
     // [0,n): camera-origin records; [n,2n): general records; then mat0[n] (float4), mat1[n] (float2)
     extern __shared__ float4 lds_rec[];
