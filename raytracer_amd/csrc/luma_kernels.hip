@@ -647,8 +647,8 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
 // (conflict free: 16 B per lane, contiguous).  Every lane does useful work on every scan
 // instruction whatever the divergence of the paths; rays that do not exist are simply not
 // scanned.  Each lane keeps the best (t, index) among its own spheres (its indices ascend, so
-// the strict `<` of Renderer.cpp:266 holds), and a 6-step butterfly over the packed key
-// (t bits << 32 | index) picks the lexicographic minimum: the smallest t, and among equal t
+// the strict `<` of Renderer.cpp:266 holds), and two wave-wide minima (DPP + v_readlane, see
+// wave_min_u32) pick the lexicographic minimum of (t, index): the smallest t, and among equal t
 // the lowest index, which is exactly what the reference's in-order scan returns.  The rest of
 // the loop (RNG, shading, accumulation) stays one lane = one pixel.
 // ---------------------------------------------------------------------------------
