@@ -112,6 +112,7 @@ def main():
     wl = WORKLOADS[a.workload]
     WIDTH, HEIGHT, SPP, BOUNCES = wl["w"], wl["h"], wl["spp"], wl["bounces"]
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL between processes needs dmabuf IPC on this driver
     import torch                                   # before abi.lib(): one shared HIP runtime
     import torch.distributed as dist
     from raytracer_amd import abi, bands
