@@ -326,6 +326,25 @@ def test_grid_gives_the_linear_scan_frame(abi, oracle, n, W, H, spp, flags, pose
         assert st.sphere_tests * 10 < st.rays * n, "the grid should skip most of a large scene"
 
 
+def test_grid_equals_linear_scan_on_a_config5_band(abi):
+    """Config #5 at full size, one of its eight stripe bands (7680 x 540 pixels, 16 spp, 4096
+    spheres): the grid path and the sphere-parallel linear scan give the same 4.1 million pixels and
+    accumulators (the linear scan itself is checked against the oracle row by row above)."""
+    W, H = 7680, 4320
+    frames = {}
+    for name, flags in (("linear", 0), ("grid", abi.FLAG_GRID)):
+        with abi.Context(0) as ctx:
+            ctx.set_scene(abi.synthetic_scene(4096))
+            ctx.set_camera(abi.default_camera(W, H))
+            ctx.set_frame_striped(W, H, 15, 3, 8)
+            img, st = ctx.render(abi.make_params(W, H, spp=16, bounces=5, paths=1, samples=1, mode=1, flags=flags, seed=SEED))
+            frames[name] = (img, ctx.read_accum(), st)
+    assert_frames_equal(frames["grid"][0], frames["linear"][0], "config #5 band, grid against linear")
+    assert np.array_equal(frames["grid"][1].view(np.uint32), frames["linear"][1].view(np.uint32))
+    assert frames["grid"][2].rays == frames["linear"][2].rays
+    assert frames["grid"][2].sphere_tests * 100 < frames["linear"][2].sphere_tests
+
+
 @pytest.mark.parametrize("kind", ["cluster_and_outliers", "line", "coincident", "shells", "flat"])
 def test_grid_on_awkward_distributions(abi, oracle, kind):
     """Scenes a uniform grid handles badly (everything in one cell, a line of cells, hundreds of
