@@ -497,6 +497,26 @@ def test_group_renders_whole_frame(abi, oracle, W, H, ids, scene_n):
     assert_frames_equal(again, first.target, "after group reset")
 
 
+@pytest.mark.parametrize("n", [2, 8])
+def test_config3_frame_cut_for_n_gpus_equals_one_gpu(abi, n):
+    """Config #3 at full size (1920x1080, 64 spp) as n interleaved-stripe bands (here all on one
+    device): the bands run the frame-splitting kernel (2 lanes per pixel at n = 2, 4 at n = 8, frames
+    claimed at run time), the whole frame runs one lane per pixel; same 2 million pixels."""
+    W, H = 1920, 1080
+    params = abi.make_params(W, H, spp=64, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    with abi.Context(0) as ctx:
+        ctx.set_scene(abi.default_scene()); ctx.set_camera(abi.default_camera(W, H)); ctx.set_frame(W, H)
+        want, wst = ctx.render(params)
+        wacc = ctx.read_accum()
+    with abi.Group([0] * n) as g:
+        g.set_scene(abi.default_scene()); g.set_camera(abi.default_camera(W, H)); g.set_frame(W, H)
+        got, st = g.render(params)
+        acc = g.read_accum()
+    assert_frames_equal(got, want, f"config #3 in {n} bands")
+    assert np.array_equal(acc.view(np.uint32), wacc.view(np.uint32))
+    assert st.rays == wst.rays
+
+
 def test_render_frame_scatters_bands_into_one_frame(abi):
     """luma_hip_render_frame: each context writes only its own rows of the shared host frame."""
     W, H, n = 80, 90, 3
