@@ -86,7 +86,8 @@ typedef struct {
     double   total_ms;      /* wall clock of the call */
     /* Work counters cover every render call on the context since the previous call that
      * returned a luma_stats (so a run of stats-less luma_hip_render_device calls can be
-     * totalled by the last one); the times are those of this call alone. */
+     * totalled by the last one; rays traced before a luma_hip_set_scene are priced at the scene
+     * they ran against); the times are those of this call alone. */
     uint64_t rays;          /* trace_ray invocations executed (Renderer.cpp:234) */
     uint64_t sphere_tests;  /* ray-sphere tests executed (loop at Renderer.cpp:242) */
 } luma_stats;
@@ -197,6 +198,10 @@ void luma_hip_host_free(void* p);
 /* Renderer::accumulated_data for the band as the reference lays it out: W*rows*3 floats,
  * AoS rgb (renderer.h:56). */
 int luma_hip_read_accum(luma_ctx* ctx, float* rgb_host);
+
+/* The band framebuffer after a luma_hip_render_device call: copies rows*width uint32 from
+ * target_dev (NULL: the context's own buffer) to target_host once the device is idle. */
+int luma_hip_read_target(luma_ctx* ctx, const uint32_t* target_dev, uint32_t* target_host);
 
 /* Frames accumulated since the last reset (== frame_count - 1, renderer.h:53). */
 int luma_hip_frame_index(luma_ctx* ctx, uint32_t* frame_index);

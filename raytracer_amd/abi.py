@@ -26,7 +26,7 @@ SYMBOLS = [
     "luma_hip_render_frame", "luma_hip_device_count", "luma_hip_group_create", "luma_hip_group_destroy",
     "luma_hip_group_size", "luma_hip_group_context", "luma_hip_group_set_scene", "luma_hip_group_set_camera",
     "luma_hip_group_set_frame", "luma_hip_group_reset", "luma_hip_group_render", "luma_hip_group_read_accum",
-    "luma_hip_host_alloc", "luma_hip_host_free", "luma_grid_describe",
+    "luma_hip_host_alloc", "luma_hip_host_free", "luma_grid_describe", "luma_hip_read_target",
 ]
 
 
@@ -90,6 +90,7 @@ def lib():
         "luma_hip_render_device": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
         "luma_hip_target_device": (C.c_int, [ctx, C.POINTER(C.c_void_p)]),
         "luma_hip_read_accum": (C.c_int, [ctx, f32p]),
+        "luma_hip_read_target": (C.c_int, [ctx, C.c_void_p, u32p]),
         "luma_hip_frame_index": (C.c_int, [ctx, u32p]),
         "luma_hip_generate_rays": (C.c_int, [ctx, f32p]),
         "luma_camera_default": (C.c_int, [C.c_float, C.c_float, C.c_float, C.c_uint32, C.c_uint32, C.POINTER(Camera)]),
@@ -292,6 +293,12 @@ class Context:
     def read_accum(self):
         out = np.empty((self.rows, self.width, 3), dtype=np.float32)
         check(lib().luma_hip_read_accum(self._h, _f32p(out)), "luma_hip_read_accum")
+        return out
+
+    def read_target(self, target_ptr=None):
+        """luma_hip_read_target: the band left in device memory by render_device, as [rows, W] uint32."""
+        out = np.empty((self.rows, self.width), dtype=np.uint32)
+        check(lib().luma_hip_read_target(self._h, target_ptr, _u32p(out)), "luma_hip_read_target")
         return out
 
     def frame_index(self):

@@ -101,8 +101,11 @@ struct luma_ctx {
 
     unsigned long long* d_counters = nullptr;  // rays traced since luma_hip_create, in kCounterSlots partial sums
     unsigned long long* h_counters = nullptr;  // pinned
-    unsigned long long rays_reported = 0;      // part of that total already handed out in a luma_stats
-    unsigned long long grid_tests_reported = 0, grid_rays_reported = 0;
+    // Counter totals already read back (drain_counters), and the work read but not yet handed out in
+    // a luma_stats.  Sphere tests of linear-scan rays are priced at the scene size they ran against,
+    // so luma_hip_set_scene drains the counters before it changes n_spheres.
+    unsigned long long rays_seen = 0, grid_tests_seen = 0, grid_rays_seen = 0;
+    unsigned long long rays_pending = 0, tests_pending = 0;
 
     // LUMA_FLAG_GRID: the spheres as given (the grid is built from them on first use) and the grid
     std::vector<luma_sphere> host_spheres;
@@ -270,7 +273,9 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
     return LUMA_OK;
 }
 
-int collect_stats(luma_ctx* ctx, hipStream_t stream, luma_stats* stats)
+// Reads the device counters (after the work queued on `stream`) and moves what is new into the
+// pending totals, priced at the current scene size.
+int drain_counters(luma_ctx* ctx, hipStream_t stream)
 {
     LUMA_HIP_TRY(hipMemcpyAsync(ctx->h_counters, ctx->d_counters, kCounterBytes, hipMemcpyDeviceToHost, stream));
     LUMA_HIP_TRY(hipStreamSynchronize(stream));
@@ -280,21 +285,29 @@ int collect_stats(luma_ctx* ctx, hipStream_t stream, luma_stats* stats)
         grid_tests += ctx->h_counters[i * luma::kCounterStride + 1];
         grid_rays += ctx->h_counters[i * luma::kCounterStride + 2];
     }
-    float ms = 0.f;
-    LUMA_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
-    stats->kernel_ms = ms;
-    stats->rays = total - ctx->rays_reported;   // since the previous luma_stats
-    ctx->rays_reported = total;
+    const unsigned long long rays = total - ctx->rays_seen;
+    const unsigned long long g_rays = grid_rays - ctx->grid_rays_seen, g_tests = grid_tests - ctx->grid_tests_seen;
+    ctx->rays_seen = total;
+    ctx->grid_rays_seen = grid_rays;
+    ctx->grid_tests_seen = grid_tests;
+    ctx->rays_pending += rays;
     // a linear-scan ray tests every sphere (Renderer.cpp:242); rays of LUMA_FLAG_GRID launches count their own
-    const unsigned long long g_rays = grid_rays - ctx->grid_rays_reported, g_tests = grid_tests - ctx->grid_tests_reported;
-    ctx->grid_rays_reported = grid_rays;
-    ctx->grid_tests_reported = grid_tests;
-    stats->sphere_tests = (stats->rays - g_rays) * ctx->n_spheres + g_tests;
+    ctx->tests_pending += (rays - g_rays) * ctx->n_spheres + g_tests;
     return LUMA_OK;
 }
 
-// Copies the band in ctx->d_target to its rows of a full host frame: contiguous bands in one
-// copy, interleaved stripes as one strided copy (chunk q of `stripe` rows lands `pitch` rows apart).
+int collect_stats(luma_ctx* ctx, hipStream_t stream, luma_stats* stats)
+{
+    if (int rc = drain_counters(ctx, stream)) { return rc; }
+    float ms = 0.f;
+    LUMA_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
+    stats->kernel_ms = ms;
+    stats->rays = ctx->rays_pending;            // since the previous luma_stats
+    stats->sphere_tests = ctx->tests_pending;
+    ctx->rays_pending = ctx->tests_pending = 0;
+    return LUMA_OK;
+}
+
 // True for memory the runtime knows as page-locked host memory (hipHostMalloc / hipHostRegister).
 bool is_page_locked(const void* p)
 {
@@ -304,6 +317,13 @@ bool is_page_locked(const void* p)
         return false;
     }
     return attr.type == hipMemoryTypeHost;
+}
+
+// A frame qualifies for the queued (async) hand-over only when its first and last byte are both
+// page-locked; a frame that is registered in part takes the blocking copies.
+bool frame_is_page_locked(const void* frame, size_t bytes)
+{
+    return bytes > 0 && is_page_locked(frame) && is_page_locked(static_cast<const char*>(frame) + bytes - 1);
 }
 
 // Copies the band in ctx->d_target to its rows of a full host frame: contiguous bands in one
@@ -415,6 +435,7 @@ int luma_hip_set_scene(luma_ctx* ctx, const luma_sphere* spheres, uint32_t n)
     if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_set_scene", "hipSetDevice failed"); }
     // launches given a caller's stream (luma_hip_render_device) may still read the old arrays
     LUMA_HIP_TRY(hipDeviceSynchronize());
+    if (ctx->rendered) { if (int rc = drain_counters(ctx, ctx->stream)) { return rc; } }   // rays so far ran against the old n
 
     free_dev(ctx->d_cx); free_dev(ctx->d_cy); free_dev(ctx->d_cz); free_dev(ctx->d_rad);
     free_dev(ctx->d_mat0); free_dev(ctx->d_mat1); free_dev(ctx->d_records);
@@ -700,6 +721,25 @@ int luma_hip_group_reset(luma_group* g)
     return LUMA_OK;
 }
 
+namespace {
+
+// After a failure in the middle of a group call: wait for every member stream, so that no copy
+// into the caller's frame (or kernel writing a band) is still in flight when the error is
+// returned and the caller frees or reuses its buffers.  Keeps the first error's message.
+int drain_group_after_error(luma_group* g, int rc)
+{
+    char keep[sizeof g_last_error];
+    std::memcpy(keep, g_last_error, sizeof keep);
+    for (luma_ctx* c : g->ctx) {
+        DeviceScope scope(c->device);
+        if (scope.ok()) { (void)hipStreamSynchronize(c->stream); }
+    }
+    std::memcpy(g_last_error, keep, sizeof keep);
+    return rc;
+}
+
+}  // namespace
+
 int luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* frame_host, luma_stats* stats)
 {
     const char* who = "luma_hip_group_render";
@@ -709,27 +749,34 @@ int luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* fr
     for (luma_ctx* c : g->ctx) { if (int rc = check_params(c, params)) { return rc; } }   // nothing launched yet
 
     const auto t0 = std::chrono::steady_clock::now();
-    for (luma_ctx* c : g->ctx) {                                   // every device starts its band ...
-        DeviceScope scope(c->device);
-        if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
-        if (int rc = enqueue_render(c, params, c->d_target, c->stream, stats != nullptr)) { return rc; }
-    }
-    // ... and hands it over as it finishes: into a page-locked frame the copies queue behind the
-    // kernels and run at the same time on every device's link, else one blocking copy per device.
-    const bool async = is_page_locked(frame_host);
-    for (luma_ctx* c : g->ctx) {
-        DeviceScope scope(c->device);
-        if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
-        if (!async) { LUMA_HIP_TRY(hipStreamSynchronize(c->stream)); }
-        if (int rc = copy_band_to_frame(c, frame_host, async)) { return rc; }
-    }
-    if (async) {
+    // the body; any failure after the first launch goes through drain_group_after_error
+    auto run = [&]() -> int {
+        for (luma_ctx* c : g->ctx) {                               // every device starts its band ...
+            DeviceScope scope(c->device);
+            if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+            if (int rc = enqueue_render(c, params, c->d_target, c->stream, stats != nullptr)) { return rc; }
+        }
+        // ... and hands it over as it finishes: into a frame that is page-locked from its first to
+        // its last byte the copies queue behind the kernels and run at the same time on every
+        // device's link, else one blocking copy per device.
+        const size_t frame_bytes = static_cast<size_t>(g->ctx[0]->width) * g->ctx[0]->height * sizeof(uint32_t);
+        const bool async = frame_is_page_locked(frame_host, frame_bytes);
         for (luma_ctx* c : g->ctx) {
             DeviceScope scope(c->device);
             if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
-            LUMA_HIP_TRY(hipStreamSynchronize(c->stream));
+            if (!async) { LUMA_HIP_TRY(hipStreamSynchronize(c->stream)); }
+            if (int rc = copy_band_to_frame(c, frame_host, async)) { return rc; }
         }
-    }
+        if (async) {
+            for (luma_ctx* c : g->ctx) {
+                DeviceScope scope(c->device);
+                if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+                LUMA_HIP_TRY(hipStreamSynchronize(c->stream));
+            }
+        }
+        return LUMA_OK;
+    };
+    if (int rc = run()) { return drain_group_after_error(g, rc); }
     const auto t1 = std::chrono::steady_clock::now();
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
@@ -786,6 +833,19 @@ int luma_hip_target_device(luma_ctx* ctx, uint32_t** target_dev)
     if (!ctx || !target_dev) { return fail(LUMA_E_ARG, "luma_hip_target_device", "null argument"); }
     if (!ctx->have_frame) { return fail(LUMA_E_STATE, "luma_hip_target_device", "luma_hip_set_frame not called"); }
     *target_dev = ctx->d_target;
+    return LUMA_OK;
+}
+
+int luma_hip_read_target(luma_ctx* ctx, const uint32_t* target_dev, uint32_t* target_host)
+{
+    const char* who = "luma_hip_read_target";
+    if (!ctx || !target_host) { return fail(LUMA_E_ARG, who, "null argument"); }
+    if (!ctx->have_frame) { return fail(LUMA_E_STATE, who, "luma_hip_set_frame not called"); }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+    LUMA_HIP_TRY(hipDeviceSynchronize());   // the latest render may have run on a caller's stream
+    LUMA_HIP_TRY(hipMemcpy(target_host, target_dev ? target_dev : ctx->d_target, ctx->band_pixels() * sizeof(uint32_t),
+                           hipMemcpyDeviceToHost));
     return LUMA_OK;
 }
 

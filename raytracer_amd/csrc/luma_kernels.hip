@@ -168,9 +168,11 @@ LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin,
     // t = num / a with num = -b - sqrt(d).  a > 0 is the same for every sphere, so candidates
     // are ordered by num and the divide is done once, for the winner.  Rounding can make two
     // different num give the same t (the reference then keeps the earlier sphere, :266), so
-    // when num is within 2^-22 of the best, or so small that num/a could flush to 0 (:258),
-    // both quotients are formed and compared exactly as the reference does.
-    const bool odd_a = !(a > 1e-30f && a < 1e30f);
+    // when num is within 2^-22 of the best, or num / a could leave the normal range (flush to 0
+    // and fail :258, or overflow past FLT_MAX and fail :266), both quotients are formed and
+    // compared exactly as the reference does: with 1e-12 < a < 1e12 and 1e-20 <= num <= 1e25
+    // the quotient lies in [1e-32, 1e37], normal and below FLT_MAX.
+    const bool odd_a = !(a > 1e-12f && a < 1e12f);
     float best_num = __builtin_inff();
     int best = -1;
 
@@ -194,7 +196,7 @@ LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin,
             const float num = -b - sqrt_rn(d);                   // :255, numerator
             if (num > 0.0f && num < best_num) {
                 bool take = true;
-                if (__builtin_expect(odd_a || num < 1e-30f || !(num < best_num * 0.99999976f), 0)) {
+                if (__builtin_expect(odd_a || !(num >= 1e-20f && num <= 1e25f) || !(num < best_num * 0.99999976f), 0)) {
                     const float t = num / a;
                     const float tb = (best < 0) ? FLT_MAX : best_num / a;
                     take = (t > 0.0f) && (t < tb);               // :258, :266
@@ -992,7 +994,9 @@ uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool
     // 259k px 0.50 / 0.36 / 0.33
     uint32_t split = band_pixels >= 1500000 ? 1u : band_pixels >= 750000 ? 2u : 4u;
     while (split > spp) { split >>= 1; }
-    if (spp > 0xFFFFu) { split = 1; }                            // the claim word holds two 16-bit counts
+    // the claim word holds two 16-bit counts, and a failed claim still increments its half: the
+    // front can reach spp + 1 and the back spp + split - 1
+    if (spp > 0x7FFFu) { split = 1; }
     return split ? split : 1u;
 }
 

@@ -132,3 +132,38 @@ def test_random_scene_matches_oracle(abi, oracle, c):
             assert diff == 0, f"{c['id']} grid, call {call}: {diff} of {W * H} pixels differ"
             assert np.array_equal(ctx.read_accum().view(np.uint32), ref.accum.view(np.uint32)), f"{c['id']} grid: accumulators"
         assert gst.rays == st.rays          # (a sphere listed in several cells may be tested more than once)
+
+
+# Degenerate caller matrices: view_inverse scaled so that |dir| is ~1e-17 .. 1e15 and
+# a = dot(dir, dir) leaves the window in which the ray-per-lane scan orders candidates by the
+# numerator alone (luma_kernels.hip scan_spheres: outside it both quotients are formed, as the
+# reference does at Renderer.cpp:255-266).  The linear, sphere-parallel and grid scans must all
+# still give the oracle's frame.
+@pytest.mark.parametrize("n", [7, 400])
+@pytest.mark.parametrize("dir_scale", [1e-17, 1e-10, 1e-7, 1e7, 1e10, 1e15])
+def test_extreme_direction_scale_all_scan_paths(abi, oracle, n, dir_scale):
+    rng = np.random.default_rng(1234 + n)
+    spheres = random_scene(rng, n, "cluster")
+    a_scene = fill((abi.Sphere * n)(), spheres, True)
+    o_scene = fill((oracle.Sphere * n)(), spheres, False)
+    W, H = 48, 20
+    a_cam, o_cam = abi.default_camera(W, H), oracle.camera(W, H)
+    for i in range(16):
+        a_cam.view_inv[i] = np.float32(a_cam.view_inv[i] * np.float32(dir_scale))
+        o_cam.view_inv[i] = a_cam.view_inv[i]
+    assert bytes(a_cam) == bytes(o_cam)
+    # noise off keeps |dir| at the scale under test (the +-blur noise would swamp a tiny dir)
+    for flags in (abi.FLAG_NOISE_OFF, 0):
+        kw = dict(spp=2, bounces=4, paths=1, samples=1, mode=1, flags=flags, seed=99)
+        ref = oracle.Renderer(o_scene, o_cam, W, H)
+        ref.render(oracle.make_params(W, H, **kw))
+        with abi.Context(0) as ctx:
+            ctx.set_scene(a_scene)
+            ctx.set_camera(a_cam)
+            ctx.set_frame(W, H)
+            for extra in (0, abi.FLAG_GRID):
+                ctx.reset()
+                got, _ = ctx.render(abi.make_params(W, H, **dict(kw, flags=flags | extra)))
+                diff = int((got != ref.target).sum())
+                assert diff == 0, f"n={n} scale={dir_scale:g} flags={flags | extra}: {diff} pixels differ"
+                assert np.array_equal(ctx.read_accum().view(np.uint32), ref.accum.view(np.uint32))

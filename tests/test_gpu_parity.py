@@ -680,7 +680,6 @@ def test_one_context_through_scene_camera_and_frame_changes(abi, oracle):
 # ---- device-resident target (what bench.py times) ------------------------------------
 
 def test_render_device_matches_host_target(abi):
-    import ctypes as C
     W, H = 100, 60
     kw = dict(spp=2, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
     host, _, _ = hip_render(abi, abi.default_scene(), abi.default_camera(W, H), W, H, **kw)
@@ -690,13 +689,28 @@ def test_render_device_matches_host_target(abi):
         ctx.set_frame(W, H)
         st = ctx.render_device(abi.make_params(W, H, **kw), want_stats=True)
         assert st.rays > 0 and st.kernel_ms > 0
-        # a second call with spp=0-equivalent is rejected; read the buffer back through render()
         ptr = ctx.target_device()
         assert ptr
-        hip = C.CDLL("libamdhip64.so.7")
-        out = np.empty((H, W), dtype=np.uint32)
-        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), C.c_void_p(ptr), out.nbytes, 2) == 0
+        out = ctx.read_target(ptr)
+        assert np.array_equal(out, ctx.read_target())
     assert_frames_equal(out, host, "device target")
+
+
+def test_stats_priced_at_the_scene_the_rays_ran_against(abi):
+    """A stats-less render, then luma_hip_set_scene, then a render with stats: the first call's rays
+    are counted against the first scene's size (the loop at Renderer.cpp:242), not the second's."""
+    W, H = 64, 32
+    kw = dict(spp=1, bounces=1, paths=0, samples=1, mode=0, flags=abi.FLAG_NOISE_OFF, seed=SEED)
+    with abi.Context(0) as ctx:
+        ctx.set_scene(abi.default_scene())                # 5 spheres
+        ctx.set_camera(abi.default_camera(W, H))
+        ctx.set_frame(W, H)
+        ctx.render_device(abi.make_params(W, H, **kw))    # no stats: W*H*2 rays against 5 spheres
+        ctx.set_scene(abi.synthetic_scene(12))
+        st = ctx.render_device(abi.make_params(W, H, **kw), want_stats=True)
+    rays_each = 2 * W * H                                 # DOF ray + one bounce ray per pixel
+    assert st.rays == 2 * rays_each
+    assert st.sphere_tests == rays_each * 5 + rays_each * 12
 
 
 # ---- error behaviour -----------------------------------------------------------------
