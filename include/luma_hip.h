@@ -144,6 +144,27 @@ int luma_hip_render(luma_ctx* ctx, const luma_params* params, uint32_t* target_h
 int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* target_dev,
                            void* stream, luma_stats* stats);
 
+/* luma_hip_render_device for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same inputs, same frame and same accumulation planes as luma_hip_render_device, bit for bit, but
+ * the scratch of its kernels (ray counters, the tile counter of large scenes, the planes in which
+ * small bands park frames that several lanes of one pixel rendered) lies in a static device array of
+ * LUMA_HIP_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds from library load to
+ * process end.  The call makes no hipMalloc / hipFree and calls no allocating routine; it returns
+ * without waiting (no luma_stats: its rays are not added to the context's counters).
+ * Limits: a call whose scratch need exceeds the array is rejected with LUMA_E_ARG and a message
+ * giving both sizes (need = 32 KiB + spp * 12 B * band pixels for bands under 1.5 M pixels of scenes
+ * under 320 spheres, 32 KiB otherwise): render the frames in several calls of fewer spp, which
+ * accumulates to the same bits.  LUMA_FLAG_GRID is rejected (LUMA_E_ARG): its tables are allocated
+ * on first use and its kernels spill registers, which makes the HIP runtime set up memory of its
+ * own at dispatch; the kernels behind every other flag use no private memory.  All calls
+ * on one GPU share the array, from any context: two such calls that overlap in time on one GPU race;
+ * keep them on one stream or order them yourself.  luma_hip_set_scene / _set_camera / _set_frame
+ * are set-up and do allocate; changing streams between calls on one context synchronises the device. */
+#define LUMA_HIP_NOALLOC_SCRATCH_BYTES (64u << 20)
+int luma_hip_render_device_noalloc(luma_ctx* ctx, const luma_params* params, uint32_t* target_dev,
+                                   void* stream);
+
 /* Device pointer of the context's own band framebuffer (valid until set_frame/destroy). */
 int luma_hip_target_device(luma_ctx* ctx, uint32_t** target_dev);
 

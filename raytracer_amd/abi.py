@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("LUMA_HIP_LIB") or os.path.join(_PKG, "libluma_hip.so"
 
 OK, E_ARG, E_HIP, E_NOMEM, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5
 MODE_RAYTRACE, MODE_PATHTRACE = 0, 1
+NOALLOC_SCRATCH_BYTES = 64 << 20
 FLAG_NOISE_OFF, FLAG_ORIGIN_FROM_HIT, FLAG_CLAMP_PACK, FLAG_NO_SHOW_DEPTH, FLAG_PACK_RGBA8, FLAG_GRID = 1, 2, 4, 8, 16, 32
 
 # every symbol include/luma_hip.h declares (checked by tests/test_abi_symbols.py)
@@ -27,6 +28,7 @@ SYMBOLS = [
     "luma_hip_group_size", "luma_hip_group_context", "luma_hip_group_set_scene", "luma_hip_group_set_camera",
     "luma_hip_group_set_frame", "luma_hip_group_reset", "luma_hip_group_render", "luma_hip_group_read_accum",
     "luma_hip_host_alloc", "luma_hip_host_free", "luma_grid_describe", "luma_hip_read_target",
+    "luma_hip_render_device_noalloc",
 ]
 
 
@@ -88,6 +90,7 @@ def lib():
         "luma_hip_reset": (C.c_int, [ctx]),
         "luma_hip_render": (C.c_int, [ctx, C.POINTER(Params), u32p, C.POINTER(Stats)]),
         "luma_hip_render_device": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
+        "luma_hip_render_device_noalloc": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.c_void_p]),
         "luma_hip_target_device": (C.c_int, [ctx, C.POINTER(C.c_void_p)]),
         "luma_hip_read_accum": (C.c_int, [ctx, f32p]),
         "luma_hip_read_target": (C.c_int, [ctx, C.c_void_p, u32p]),
@@ -284,6 +287,11 @@ class Context:
         check(lib().luma_hip_render_device(self._h, C.byref(params), target_ptr, stream,
                                            C.byref(st) if want_stats else None), "luma_hip_render_device")
         return st
+
+    def render_device_noalloc(self, params, target_ptr=None, stream=None):
+        """luma_hip_render_device_noalloc: as render_device, scratch in the library's static array."""
+        check(lib().luma_hip_render_device_noalloc(self._h, C.byref(params), target_ptr, stream),
+              "luma_hip_render_device_noalloc")
 
     def target_device(self):
         p = C.c_void_p()

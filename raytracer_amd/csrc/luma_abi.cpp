@@ -99,6 +99,8 @@ struct luma_ctx {
     float* d_split = nullptr;      // parked frames of split renders (luma_kernels.hip, SPLIT), grown on demand
     size_t split_bytes = 0;
 
+    unsigned char* static_scratch = nullptr;   // this device's copy of luma_kernels.hip's `scratch` (render_device_noalloc)
+
     unsigned long long* d_counters = nullptr;  // rays traced since luma_hip_create, in kCounterSlots partial sums
     unsigned long long* h_counters = nullptr;  // pinned
     // Counter totals already read back (drain_counters), and the work read but not yet handed out in
@@ -406,6 +408,10 @@ int luma_hip_create(luma_ctx** out, int device_id)
     if ((e = hipMalloc(&ctx->d_counters, kCounterAlloc)) != hipSuccess) { return bail(e, "hipMalloc(counters)"); }
     if ((e = hipHostMalloc(&ctx->h_counters, kCounterBytes)) != hipSuccess) { return bail(e, "hipHostMalloc(counters)"); }
     if ((e = hipMemset(ctx->d_counters, 0, kCounterAlloc)) != hipSuccess) { return bail(e, "hipMemset(counters)"); }
+    // the device is current here: this is the address of the static scratch array on THIS GPU
+    void* scratch_ptr = nullptr;
+    if ((e = luma::static_scratch_address(&scratch_ptr)) != hipSuccess) { return bail(e, "hipGetSymbolAddress(scratch)"); }
+    ctx->static_scratch = static_cast<unsigned char*>(scratch_ptr);
     *out = ctx;
     return LUMA_OK;
 }
@@ -599,6 +605,55 @@ int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* t
         if (int rc = collect_stats(ctx, s, stats)) { return rc; }
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
+    return LUMA_OK;
+}
+
+static_assert(luma::kStaticScratchBytes == LUMA_HIP_NOALLOC_SCRATCH_BYTES, "header and kernels disagree on the static scratch size");
+static_assert(kCounterAlloc <= luma::kStaticCounterBytes, "counter block does not fit its part of the static scratch");
+
+int luma_hip_render_device_noalloc(luma_ctx* ctx, const luma_params* params, uint32_t* target_dev, void* stream)
+{
+    const char* who = "luma_hip_render_device_noalloc";
+    if (int rc = check_params(ctx, params)) { return rc; }
+    if (!ctx->static_scratch) { return fail(LUMA_E_STATE, who, "static scratch address not resolved"); }
+    if (params->flags & LUMA_FLAG_GRID) {
+        // the grid tables are built (allocated) on first use, and the grid kernels spill registers,
+        // for which the HIP runtime itself sets up per-queue memory at dispatch
+        return fail(LUMA_E_ARG, who, "LUMA_FLAG_GRID is not available without allocation; use luma_hip_render_device");
+    }
+    const bool grid = false;
+    // the scratch this call needs, against the fixed size of the static array
+    const uint32_t split = luma::choose_split(ctx->band_pixels(), params->spp, ctx->n_spheres, grid);
+    const unsigned long long parking = split > 1
+        ? static_cast<unsigned long long>(params->spp) * 3ull * ctx->band_pixels() * sizeof(float) : 0ull;
+    if (luma::kStaticCounterBytes + parking > luma::kStaticScratchBytes) {
+        char msg[256];
+        std::snprintf(msg, sizeof msg,
+                      "spp %u x %zu band pixels needs %llu bytes of scratch, the static array holds %zu "
+                      "(LUMA_HIP_NOALLOC_SCRATCH_BYTES): render the frames in several calls of fewer spp",
+                      params->spp, ctx->band_pixels(), luma::kStaticCounterBytes + parking, luma::kStaticScratchBytes);
+        return fail(LUMA_E_ARG, who, msg);
+    }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    if (int rc = order_after_previous(ctx, s)) { return rc; }
+    if (int rc = refresh_records(ctx, s)) { return rc; }          // a launch into memory luma_hip_set_scene allocated
+
+    luma::RenderArgs args = make_args(ctx, params, target_dev ? target_dev : ctx->d_target);
+    unsigned char* const scratch = ctx->static_scratch;          // the device pointer, never the array's name
+    args.counters = reinterpret_cast<unsigned long long*>(scratch);
+    args.tile_counter = reinterpret_cast<uint32_t*>(scratch + kCounterBytes);
+    args.split = split;
+    args.split_scratch = split > 1 ? reinterpret_cast<float*>(scratch + luma::kStaticCounterBytes) : nullptr;
+    // every call on this GPU shares the array and finds the previous call's contents in it: the
+    // counters (the tile counter must start at zero) are cleared; the parking planes need no
+    // clearing, every slot that is read was written earlier in the same launch
+    LUMA_HIP_TRY(hipMemsetAsync(scratch, 0, kCounterAlloc, s));
+    LUMA_HIP_TRY(luma::launch_render(args, s));
+    ctx->frame_index += params->spp;
+    ctx->last_stream = s;
+    ctx->rendered = true;
     return LUMA_OK;
 }
 

@@ -75,6 +75,16 @@ struct RenderArgs {
     GridArgs  grid;                // only read under FLAG_GRID
 };
 
+// luma_hip_render_device_noalloc: the scratch of the render kernels (ray counters, the tile counter
+// of the sphere-parallel kernel, the parking planes of SPLIT renders) in one file-scope __device__
+// array of luma_kernels.hip instead of hipMalloc memory.  Layout: [0, kStaticCounterBytes) counters
+// + tile counter, [kStaticCounterBytes, kStaticScratchBytes) parking planes.
+static constexpr size_t kStaticScratchBytes = size_t(64) << 20;   // == LUMA_HIP_NOALLOC_SCRATCH_BYTES
+static constexpr size_t kStaticCounterBytes = 32 * 1024;
+// Device address of that array on the CURRENT device (each GPU holds its own copy at its own
+// address); looked up once per device with hipGetSymbolAddress and kept.
+hipError_t static_scratch_address(void** ptr);
+
 size_t     scene_lds_bytes(uint32_t n_spheres);
 bool       sphere_parallel_scene(uint32_t n_spheres);
 uint32_t   choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid);

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 namespace luma {
@@ -998,6 +999,36 @@ uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool
     // front can reach spp + 1 and the back spp + split - 1
     if (spp > 0x7FFFu) { split = 1; }
     return split ? split : 1u;
+}
+
+// ---------------------------------------------------------------------------------
+// Scratch of luma_hip_render_device_noalloc (include/luma_hip.h): device memory that exists from
+// the moment the code object is loaded, so that entry point never calls hipMalloc.  In host code
+// the name `scratch` is only a handle for hipGetSymbolAddress, never a device address: kernels get
+// the pointer that static_scratch_address() returns, as they get hipMalloc'ed buffers elsewhere.
+// ---------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+hipError_t static_scratch_address(void** ptr)
+{
+    constexpr int kMaxDevices = 64;
+    static std::mutex lock;
+    static void* per_device[kMaxDevices] = {};                   // each GPU has its own copy of the array
+    *ptr = nullptr;
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { return e; }
+    if (dev < 0 || dev >= kMaxDevices) { return hipErrorInvalidDevice; }
+    std::lock_guard<std::mutex> guard(lock);
+    if (!per_device[dev]) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));        // address on the current device
+        if (e != hipSuccess) { return e; }
+        if (!p) { return hipErrorInvalidSymbol; }
+        per_device[dev] = p;
+    }
+    *ptr = per_device[dev];
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------
