@@ -13,7 +13,10 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,16 +37,56 @@ WORKLOADS = {
 }
 FLOP_PER_TEST, FLOP_PER_RAY = 17.0, 64.0          # SURVEY.md 8d / BASELINE.md section 5
 PEAK_FP32_VALU_TFLOPS = 157.3                     # MI355X_MICROARCH.md, "Peak FP32 (vector)"
+# "confirm by FMA microbenchmark on the box and use the measured figure if lower".
+# tools/ubench_valu.hip (v_pk_fma_f32, 8 waves/SIMD, every CU) on MI355X: profiles/r01/ubench_valu.txt.
+PEAK_FP32_VALU_MEASURED_TFLOPS = 121.0
+PEAK_MEASURED_SOURCE = "tools/ubench_valu.hip, profiles/r01/ubench_valu.txt (commit 8fe0062)"
 
 
 def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/r01/traffic.json: FETCH_SIZE x2 for gfx950 + WRITE_SIZE), or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
-            return json.load(f).get(workload, {}).get("corrected_bytes")
-    except (OSError, ValueError):
-        return None
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 for
+    gfx950 + WRITE_SIZE), newest round first, with the commit the passes were taken at: a
+    committed measurement, not a counter of this run.  (bytes, source) or (None, None)."""
+    for rnd in ("r02", "r01"):
+        try:
+            with open(os.path.join(ROOT, "profiles", rnd, "traffic.json")) as f:
+                doc = json.load(f)
+        except (OSError, ValueError):
+            continue
+        entry = doc.get(workload, {})
+        if entry.get("corrected_bytes") is not None:
+            return entry["corrected_bytes"], f"profiles/{rnd}/traffic.json @ {doc.get('commit', 'round-1 kernels (30d299c)')}"
+    return None, None
+
+
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` from a plain shell: start the N rank processes ourselves.  This parent
+    has made no GPU call and imported no torch; each rank is a fresh child (never an exec of a
+    process that touched the GPU).  Rank 0's child prints the JSON line; the exit code is non-zero
+    if any rank fails, and the others are then stopped by their own PIDs."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:                     # a rank died: the rest would wait in a collective forever
+                    q.terminate()
+    return rc if rc >= 0 else 1
 
 
 def cpu_baseline(seconds_target=10.0, threads_all=None):
@@ -54,6 +97,19 @@ def cpu_baseline(seconds_target=10.0, threads_all=None):
     from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_binding as ob
+    # the baseline leg is built for THIS host (-O3 -march=native); the
+    # in-tree library (oracle/Makefile, -O2 -march=x86-64-v3, portable) is the fallback.  The
+    # arithmetic contract (-ffp-contract=off, explicit fmaf) is the same, so are the frames.
+    flags = "-O2 -std=c99 -ffp-contract=off -fno-fast-math -march=x86-64-v3 (oracle/Makefile, prebuilt)"
+    try:
+        native = os.path.join(tempfile.mkdtemp(prefix="luma_oracle_"), "libluma_oracle_native.so")
+        opt = ["-O3", "-std=c99", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-march=native"]
+        subprocess.check_call(["gcc"] + opt + ["-shared", "-o", native, os.path.join(ob.ORACLE_DIR, "luma_oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
+        ob.ORACLE_SO = native
+        flags = "gcc " + " ".join(opt) + " (built on this host for this leg)"
+    except (OSError, subprocess.SubprocessError):
+        pass
     cam, scene = ob.camera(WIDTH, HEIGHT), ob.default_scene()
     p = ob.make_params(WIDTH, HEIGHT, spp=SPP, bounces=BOUNCES, paths=PATHS, samples=SAMPLES, mode=1, seed=SEED)
 
@@ -71,7 +127,7 @@ def cpu_baseline(seconds_target=10.0, threads_all=None):
         if time.perf_counter() - t0 > seconds_target:
             break
     dt = time.perf_counter() - t0
-    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port",
+    out = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": 1, "kind": "port", "flags": flags,
            "sample": f"{rows} of {HEIGHT} rows (4-row groups every 8 rows, time-capped) x {WIDTH} px x {SPP} spp, "
                      f"{rays} rays in {dt:.2f} s",
            "msamples_per_s": rows * WIDTH * SPP / dt / 1e6}
@@ -107,7 +163,13 @@ def main():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks "
                          "(bands are gathered through host memory; not a measurement)")
+    ap.add_argument("--selftest-spawn", action="store_true",
+                    help="no GPU work: the ranks rendezvous (gloo), all-reduce their rank numbers, rank 0 prints "
+                         "the sum; checks the launcher path of --gpus N on a box without GPUs")
+    ap.add_argument("--selftest-fail-rank", type=int, default=-1, help="with --selftest-spawn: this rank exits 3 instead")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))       # before any torch import or GPU call
     global WIDTH, HEIGHT, SPP, BOUNCES
     wl = WORKLOADS[a.workload]
     WIDTH, HEIGHT, SPP, BOUNCES = wl["w"], wl["h"], wl["spp"], wl["bounces"]
@@ -121,7 +183,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
+    if a.selftest_spawn:
+        if rank == a.selftest_fail_rank:
+            raise SystemExit(3)
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank], dtype=torch.int64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"spawn_selftest": {"world": world, "rank_sum": int(t[0])}}), flush=True)
+        dist.destroy_process_group()
+        return
+    if torch.cuda.device_count() == 0:
+        raise SystemExit("bench.py: no GPU visible (the render loop has no CPU fallback)")
     rehearsal = a.dist_backend == "gloo"
     if rehearsal:
         local %= torch.cuda.device_count()
@@ -206,13 +280,45 @@ def main():
     rays_per_launch = st.rays / (a.steps + 1)      # a.steps timed launches + the stats launch itself
     tests_per_launch = st.sphere_tests / (a.steps + 1)
 
-    t = torch.tensor([dt, rays_per_launch, tests_per_launch, kernel_ms], dtype=torch.float64, device=red_dev)
+    # frame leg (SURVEY 8d "frame ms", what the reference itself times: one whole render_to,
+    # main.cpp:261-276): wall clock of one call that ends with the finished frame in HOST memory.
+    # One GPU: luma_hip_render into a page-locked frame (kernel + D2H).  N ranks: render, gather of
+    # the bands on rank 0 (not pipelined: the frame is waited for), D2H of the assembled frame.
+    n_frame = max(1, min(a.steps, 20))
+    if world == 1 and not a.force_dist:
+        with abi.HostFrame(y1 - y0, WIDTH) as hf:
+            ctx.render(params, want_stats=False, out=hf.array)    # first touch of the frame
+            t1 = time.perf_counter()
+            for _ in range(n_frame):
+                ctx.render(params, want_stats=False, out=hf.array)
+            frame_ms = (time.perf_counter() - t1) / n_frame * 1e3
+    else:
+        host = torch.empty((HEIGHT, WIDTH), dtype=torch.int32).pin_memory() if rank == 0 and not rehearsal else None
+
+        def whole_frame():
+            ctx.render_device(params, band.data_ptr(), stream.cuda_stream)
+            send = band.cpu() if rehearsal else band
+            full = (bands.gather_striped(send, HEIGHT, WIDTH, rank, world, stripe) if stripe
+                    else bands.gather_frame(send, HEIGHT, WIDTH, rank, world))
+            if host is not None and full is not None and full.numel() == host.numel():
+                host.copy_(full.reshape(HEIGHT, WIDTH), non_blocking=True)
+            torch.cuda.synchronize()
+
+        whole_frame()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(n_frame):
+            whole_frame()
+        fence()
+        frame_ms = (time.perf_counter() - t1) / n_frame * 1e3
+
+    t = torch.tensor([dt, rays_per_launch, tests_per_launch, kernel_ms, frame_ms], dtype=torch.float64, device=red_dev)
     if use_dist:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, kernel_ms = float(tmax[0]), float(tmax[3])
+        dt, kernel_ms, frame_ms = float(tmax[0]), float(tmax[3]), float(tmax[4])
         rays_per_step, tests_per_step = float(tsum[1]), float(tsum[2])
     else:
         rays_per_step, tests_per_step = rays_per_launch, tests_per_launch
@@ -222,6 +328,7 @@ def main():
         value = rays_per_step * a.steps / dt / 1e6
         flop = FLOP_PER_TEST * tests_per_launch + FLOP_PER_RAY * rays_per_launch   # rank 0's launch
         achieved = flop / (kernel_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(a.workload)
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -231,7 +338,11 @@ def main():
                        "parallelism": ("one GPU, whole frame" if world == 1 and not a.emulate_world
                                        else f"{world} ranks, interleaved {stripe}-row stripes, RCCL gather to rank 0" if world > 1 and stripe
                                        else f"{world} scanline band(s), RCCL gather to rank 0")},
-            "frame_ms": ms_per_step,
+            # ms_per_step (and value) time the step with the frame left in HBM, as the bench contract
+            # asks; frame_ms is the host-target frame: kernel + (gather) + D2H into page-locked memory
+            "frame_ms": frame_ms,
+            "frame_ms_definition": ("wall of luma_hip_render into a page-locked host frame (kernel + D2H)" if world == 1 and not a.force_dist
+                                    else "wall of render + gather of the bands on rank 0 + D2H of the frame, not pipelined, max over ranks"),
             "msamples_per_s": WIDTH * (HEIGHT // (a.emulate_world or 1)) * SPP * a.steps / dt / 1e6,
             "rays_per_step": rays_per_step,
             # the reference traces the noise-free DOF ray once per frame (Renderer.cpp:416); the kernels
@@ -242,8 +353,10 @@ def main():
             "kernel_ms": kernel_ms,
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
-                         "traffic": measured_traffic(a.workload) if world == 1 and not a.emulate_world else None,
-                         "traffic_unit": "bytes/launch (rocprofv3 PMC, profiles/r01/traffic.json)",
+                         "peak_measured": PEAK_FP32_VALU_MEASURED_TFLOPS, "peak_measured_source": PEAK_MEASURED_SOURCE,
+                         "frac_of_measured": achieved / PEAK_FP32_VALU_MEASURED_TFLOPS,
+                         "traffic": traffic if world == 1 and not a.emulate_world else None,
+                         "traffic_unit": "bytes/launch, rocprofv3 PMC passes committed at " + str(traffic_src),
                          "algorithmic_bytes": 28 * WIDTH * (y1 - y0),
                          "kernel": "luma::render_kernel", "flop_model": "17*sphere_tests + 64*rays (SURVEY 8d)"},
         }

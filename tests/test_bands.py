@@ -9,6 +9,8 @@ import pytest
 
 from raytracer_amd import bands
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_band_rows_partition():
     for H in (1080, 2160, 4320, 104, 7):
@@ -169,3 +171,32 @@ def test_two_rank_gather_equals_full_frame(H):
         assert p.exitcode == 0
     full, _, _ = ob.render(ob.default_scene(), ob.camera(W, H), ob.make_params(W, H, spp=2, bounces=5, mode=1, seed=0x4C554D41))
     assert np.array_equal(frame, full)
+
+
+# ---- bench.py --gpus N from a plain shell: the launcher path (no GPU needed) ----------
+
+def _run_bench(*args, timeout=120):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_starts_its_own_ranks():
+    """WORLD_SIZE unset and --gpus 2: bench.py spawns two rank processes itself (before any torch
+    import in the parent), they rendezvous on 127.0.0.1, and rank 0 alone prints the JSON line."""
+    import json
+    r = _run_bench("--gpus", "2", "--selftest-spawn")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    assert json.loads(lines[0]) == {"spawn_selftest": {"world": 2, "rank_sum": 1}}
+
+
+def test_bench_launcher_fails_when_a_rank_fails():
+    """A rank that dies must not leave the others waiting in a collective: the parent stops them
+    (by PID) and exits non-zero."""
+    r = _run_bench("--gpus", "3", "--selftest-spawn", "--selftest-fail-rank", "1", timeout=90)
+    assert r.returncode == 3
+    assert "spawn_selftest" not in r.stdout
