@@ -182,8 +182,8 @@ int luma_hip_render_frame(luma_ctx* ctx, const luma_params* params, uint32_t* fr
  * frame together: the frame is cut into interleaved 15-row stripes when height divides by
  * 15*n, else into contiguous scanline bands; every device renders its part on its own stream at
  * the same time and copies it straight into the caller's host frame over its own PCIe link (the
- * reference's target is host memory, so no device-to-device gather is needed; the
- * one-process-per-GPU path with a RCCL gather is bench.py's).  The frame is bit-identical to a
+ * reference's target is host memory, so no device-to-device gather is needed;
+ * luma_hip_group_render_device below gathers the bands on one GPU over RCCL instead).  The frame is bit-identical to a
  * one-device render.  A device id may repeat (several bands on one GPU; used by the tests).
  * No counterpart in the reference, which is single-threaded CPU code. */
 typedef struct luma_group luma_group;
@@ -201,6 +201,24 @@ int  luma_hip_group_reset(luma_group* g);
  * (devices may have advanced unevenly). */
 int  luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* frame_host,
                            luma_stats* stats);
+/* Renderer::render_to over the whole frame with the frame assembled in DEVICE memory of the root (the
+ * first member's device), for consumers that keep it on the GPU (the reference's own
+ * target is host memory, Renderer.cpp:461, which luma_hip_group_render serves without any gather).
+ * Every device renders its band; then one grouped RCCL exchange over one communicator for the group's
+ * devices (ncclCommInitAll at first use) moves the bands: each member ncclSend's its band from its own
+ * device, the root ncclRecv's them, contiguous bands straight into their rows of the frame, stripe
+ * bands into a staging buffer that one kernel then puts in row order.  frame_dev: width*height uint32
+ * on the root's device, or NULL for the group's own frame (luma_hip_group_frame_device).  Synchronous:
+ * the frame is complete on return.  Bit-identical to a one-device luma_hip_render_device.  gather_ms is
+ * the exchange (and de-interleave) on the root, from HIP events.  RCCL is bound at first use
+ * (librccl.so.1); LUMA_E_RCCL if that fails or a RCCL call does.  A device id may repeat in the group:
+ * its members share that device's communicator rank. */
+int  luma_hip_group_render_device(luma_group* g, const luma_params* params, uint32_t* frame_dev,
+                                  luma_stats* stats);
+/* The group's own frame on the root device (allocated on first use, valid until the group is destroyed
+ * or its frame grows), and a copy of it to host memory. */
+int  luma_hip_group_frame_device(luma_group* g, uint32_t** frame_dev);
+int  luma_hip_group_read_frame(luma_group* g, uint32_t* frame_host);
 /* Renderer::accumulated_data of the whole frame (width*height*3 floats, AoS rgb, renderer.h:56),
  * put together from the members' bands. */
 int  luma_hip_group_read_accum(luma_group* g, float* rgb_host);

@@ -29,6 +29,7 @@ SYMBOLS = [
     "luma_hip_group_set_frame", "luma_hip_group_reset", "luma_hip_group_render", "luma_hip_group_read_accum",
     "luma_hip_host_alloc", "luma_hip_host_free", "luma_grid_describe", "luma_hip_read_target",
     "luma_hip_render_device_noalloc",
+    "luma_hip_group_render_device", "luma_hip_group_frame_device", "luma_hip_group_read_frame",
 ]
 
 
@@ -113,6 +114,9 @@ def lib():
         "luma_hip_group_reset": (C.c_int, [ctx]),
         "luma_hip_group_render": (C.c_int, [ctx, C.POINTER(Params), u32p, C.POINTER(Stats)]),
         "luma_hip_group_read_accum": (C.c_int, [ctx, f32p]),
+        "luma_hip_group_render_device": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]),
+        "luma_hip_group_frame_device": (C.c_int, [ctx, C.POINTER(C.c_void_p)]),
+        "luma_hip_group_read_frame": (C.c_int, [ctx, u32p]),
         "luma_hip_host_alloc": (C.c_int, [ctxp, C.c_size_t]),
         "luma_hip_host_free": (None, [C.c_void_p]),
         "luma_grid_describe": (C.c_int, [C.POINTER(Sphere), C.c_uint32, C.POINTER(GridInfo), u32p, u32p, u32p]),
@@ -370,6 +374,23 @@ class Group:
     def read_accum(self):
         out = np.empty((self.height, self.width, 3), dtype=np.float32)
         check(lib().luma_hip_group_read_accum(self._h, _f32p(out)), "luma_hip_group_read_accum")
+        return out
+
+    def render_device(self, params, frame_ptr=None, want_stats=True):
+        """luma_hip_group_render_device: bands gathered on the root GPU over RCCL.  Returns Stats."""
+        st = Stats()
+        check(lib().luma_hip_group_render_device(self._h, C.byref(params), frame_ptr, C.byref(st) if want_stats else None),
+              "luma_hip_group_render_device")
+        return st
+
+    def frame_device(self):
+        p = C.c_void_p()
+        check(lib().luma_hip_group_frame_device(self._h, C.byref(p)), "luma_hip_group_frame_device")
+        return p.value
+
+    def read_frame(self):
+        out = np.empty((self.height, self.width), dtype=np.uint32)
+        check(lib().luma_hip_group_read_frame(self._h, _u32p(out)), "luma_hip_group_read_frame")
         return out
 
     def render(self, params, want_stats=True, out=None):

@@ -14,6 +14,7 @@
 #include "luma_grid.h"
 #include "luma_host.h"
 #include "luma_kernels.h"
+#include "luma_rccl.h"
 
 namespace {
 
@@ -356,9 +357,29 @@ int copy_band_to_frame(const luma_ctx* ctx, uint32_t* frame_host, bool async)
 
 }  // namespace
 
+// What luma_hip_group_render_device needs beyond the member contexts: one RCCL communicator rank
+// and one stream per DISTINCT device of the group (the root's device is rank 0), an event per member
+// that says "band rendered", and on the root a staging buffer for interleaved-stripe bands plus the
+// group's own frame.  Built on first use, torn down with the group.
+struct GroupGather {
+    std::vector<int> devices;              // distinct devices, [0] = device of member 0 = the root
+    std::vector<int> rank_of_member;       // member -> index into devices / comms / streams
+    std::vector<ncclComm_t> comms;
+    std::vector<hipStream_t> streams;      // the stream each communicator rank's sends / receives run on
+    std::vector<hipEvent_t> rendered;      // per member, recorded on the member's stream
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;   // around the exchange, on the root's stream
+    uint32_t* staging = nullptr;           // root device; striped partitions only
+    size_t staging_bytes = 0;
+    uint32_t* frame = nullptr;             // root device; the group's own frame (frame_dev == NULL)
+    size_t frame_bytes = 0;
+    bool ready = false;
+};
+
 struct luma_group {
     std::vector<luma_ctx*> ctx;
     bool have_frame = false;
+    bool striped = false;
+    GroupGather gather;
 };
 
 extern "C" {
@@ -709,9 +730,54 @@ int luma_hip_group_create(luma_group** out, int n, const int* device_ids)
     return LUMA_OK;
 }
 
+namespace {
+
+// Communicator ranks, their streams and the events (also after a first use that failed half way).
+void destroy_gather_comms(luma_group* g)
+{
+    GroupGather& G = g->gather;
+    const luma::RcclApi* rccl = luma::rccl_api(nullptr);
+    for (size_t r = 0; r < G.devices.size(); r++) {
+        DeviceScope scope(G.devices[r]);
+        if (!scope.ok()) { continue; }
+        if (r < G.streams.size() && G.streams[r]) { (void)hipStreamSynchronize(G.streams[r]); }
+        if (rccl && r < G.comms.size() && G.comms[r]) { (void)rccl->CommDestroy(G.comms[r]); }
+        if (r < G.streams.size() && G.streams[r]) { (void)hipStreamDestroy(G.streams[r]); }
+    }
+    for (size_t i = 0; i < G.rendered.size(); i++) {
+        if (!G.rendered[i]) { continue; }
+        DeviceScope scope(g->ctx[i]->device);
+        if (scope.ok()) { (void)hipEventDestroy(G.rendered[i]); }
+    }
+    if (!G.devices.empty()) {
+        DeviceScope scope(G.devices[0]);
+        if (scope.ok()) {
+            if (G.ev_begin) { (void)hipEventDestroy(G.ev_begin); }
+            if (G.ev_end) { (void)hipEventDestroy(G.ev_end); }
+        }
+    }
+    G.devices.clear(); G.rank_of_member.clear(); G.comms.clear(); G.streams.clear(); G.rendered.clear();
+    G.ev_begin = G.ev_end = nullptr;
+    G.ready = false;
+}
+
+void destroy_gather(luma_group* g)
+{
+    destroy_gather_comms(g);
+    GroupGather& G = g->gather;
+    if (!g->ctx.empty() && (G.staging || G.frame)) {
+        DeviceScope scope(g->ctx[0]->device);
+        if (scope.ok()) { free_dev(G.staging); free_dev(G.frame); }
+    }
+    G.staging_bytes = G.frame_bytes = 0;
+}
+
+}  // namespace
+
 void luma_hip_group_destroy(luma_group* g)
 {
     if (!g) { return; }
+    destroy_gather(g);
     for (luma_ctx* c : g->ctx) { luma_hip_destroy(c); }
     delete g;
 }
@@ -766,6 +832,7 @@ int luma_hip_group_set_frame(luma_group* g, uint32_t width, uint32_t height)
         if (rc) { return rc; }
     }
     g->have_frame = true;
+    g->striped = striped;
     return LUMA_OK;
 }
 
@@ -847,6 +914,215 @@ int luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* fr
         // kernels and copies of different devices overlap: the copy share is what the slowest kernel leaves
         const double all_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
         stats->gather_ms = all_ms > stats->kernel_ms ? all_ms - stats->kernel_ms : 0.0;
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return LUMA_OK;
+}
+
+namespace {
+
+#define LUMA_RCCL_TRY(api, expr)                                                   \
+    do {                                                                           \
+        ncclResult_t r_ = (expr);                                                  \
+        if (r_ != ncclSuccess) { return fail(LUMA_E_RCCL, #expr, (api)->GetErrorString(r_)); } \
+    } while (0)
+
+// First use: one communicator over the distinct devices of the group (ncclCommInitAll, SURVEY 8e:
+// one process, N devices), a stream per rank, an event per member.
+int ensure_gather(luma_group* g)
+{
+    GroupGather& G = g->gather;
+    if (G.ready) { return LUMA_OK; }
+    const char* why = "";
+    const luma::RcclApi* rccl = luma::rccl_api(&why);
+    if (!rccl) { return fail(LUMA_E_RCCL, "RCCL is not available", why); }
+    destroy_gather_comms(g);                                        // leftovers of a first use that failed
+    try {
+        for (luma_ctx* c : g->ctx) {
+            size_t r = 0;
+            while (r < G.devices.size() && G.devices[r] != c->device) { r++; }
+            if (r == G.devices.size()) { G.devices.push_back(c->device); }
+            G.rank_of_member.push_back(static_cast<int>(r));
+        }
+        G.comms.assign(G.devices.size(), nullptr);
+        G.streams.assign(G.devices.size(), nullptr);
+        G.rendered.assign(g->ctx.size(), nullptr);
+    } catch (...) {
+        return fail(LUMA_E_NOMEM, "luma_hip_group_render_device", "host allocation failed");
+    }
+    LUMA_RCCL_TRY(rccl, rccl->CommInitAll(G.comms.data(), static_cast<int>(G.devices.size()), G.devices.data()));
+    for (size_t r = 0; r < G.devices.size(); r++) {
+        DeviceScope scope(G.devices[r]);
+        if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_group_render_device", "hipSetDevice failed"); }
+        LUMA_HIP_TRY(hipStreamCreateWithFlags(&G.streams[r], hipStreamNonBlocking));
+        if (r == 0) {
+            LUMA_HIP_TRY(hipEventCreate(&G.ev_begin));
+            LUMA_HIP_TRY(hipEventCreate(&G.ev_end));
+        }
+    }
+    for (size_t i = 0; i < g->ctx.size(); i++) {
+        DeviceScope scope(g->ctx[i]->device);
+        if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_group_render_device", "hipSetDevice failed"); }
+        LUMA_HIP_TRY(hipEventCreateWithFlags(&G.rendered[i], hipEventDisableTiming));
+    }
+    G.ready = true;
+    return LUMA_OK;
+}
+
+// Root-device buffer of at least `bytes`, grown on demand (set-up, not per frame).
+int ensure_root_buffer(luma_group* g, uint32_t*& buf, size_t& have, size_t bytes)
+{
+    if (have >= bytes) { return LUMA_OK; }
+    DeviceScope scope(g->ctx[0]->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, "luma_hip_group_render_device", "hipSetDevice failed"); }
+    LUMA_HIP_TRY(hipDeviceSynchronize());
+    free_dev(buf);
+    have = 0;
+    LUMA_HIP_TRY(hipMalloc(&buf, bytes));
+    have = bytes;
+    return LUMA_OK;
+}
+
+}  // namespace
+
+int luma_hip_group_frame_device(luma_group* g, uint32_t** frame_dev)
+{
+    const char* who = "luma_hip_group_frame_device";
+    if (!g || !frame_dev) { return fail(LUMA_E_ARG, who, "null argument"); }
+    if (!g->have_frame) { return fail(LUMA_E_STATE, who, "luma_hip_group_set_frame not called"); }
+    const size_t bytes = static_cast<size_t>(g->ctx[0]->width) * g->ctx[0]->height * sizeof(uint32_t);
+    if (int rc = ensure_root_buffer(g, g->gather.frame, g->gather.frame_bytes, bytes)) { return rc; }
+    *frame_dev = g->gather.frame;
+    return LUMA_OK;
+}
+
+int luma_hip_group_read_frame(luma_group* g, uint32_t* frame_host)
+{
+    const char* who = "luma_hip_group_read_frame";
+    if (!g || !frame_host) { return fail(LUMA_E_ARG, who, "null argument"); }
+    if (!g->have_frame || !g->gather.frame) { return fail(LUMA_E_STATE, who, "no frame gathered yet (luma_hip_group_render_device with frame_dev == NULL)"); }
+    DeviceScope scope(g->ctx[0]->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+    const size_t bytes = static_cast<size_t>(g->ctx[0]->width) * g->ctx[0]->height * sizeof(uint32_t);
+    LUMA_HIP_TRY(hipMemcpy(frame_host, g->gather.frame, bytes, hipMemcpyDeviceToHost));
+    return LUMA_OK;
+}
+
+int luma_hip_group_render_device(luma_group* g, const luma_params* params, uint32_t* frame_dev, luma_stats* stats)
+{
+    const char* who = "luma_hip_group_render_device";
+    if (!g) { return fail(LUMA_E_ARG, who, "null group"); }
+    if (!g->have_frame) { return fail(LUMA_E_STATE, who, "luma_hip_group_set_frame not called"); }
+    for (luma_ctx* c : g->ctx) { if (int rc = check_params(c, params)) { return rc; } }   // nothing launched yet
+    luma_ctx* const root = g->ctx[0];
+    const size_t width = root->width, frame_bytes = width * root->height * sizeof(uint32_t);
+    if (frame_dev) {
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, frame_dev) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != root->device) {
+            (void)hipGetLastError();
+            return fail(LUMA_E_ARG, who, "frame_dev must be device memory of the root (the first member's device)");
+        }
+    } else {
+        if (int rc = luma_hip_group_frame_device(g, &frame_dev)) { return rc; }
+    }
+    if (int rc = ensure_gather(g)) { return rc; }
+    GroupGather& G = g->gather;
+    if (g->striped) { if (int rc = ensure_root_buffer(g, G.staging, G.staging_bytes, frame_bytes)) { return rc; } }
+    const luma::RcclApi* rccl = luma::rccl_api(nullptr);
+
+    const auto t0 = std::chrono::steady_clock::now();
+    auto run = [&]() -> int {
+        // every device renders its band on its context's stream and marks the end with an event ...
+        for (size_t i = 0; i < g->ctx.size(); i++) {
+            luma_ctx* c = g->ctx[i];
+            DeviceScope scope(c->device);
+            if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+            if (int rc = enqueue_render(c, params, c->d_target, c->stream, stats != nullptr)) { return rc; }
+            LUMA_HIP_TRY(hipEventRecord(G.rendered[i], c->stream));
+        }
+        // ... the exchange stream of each device waits for the bands rendered on that device ...
+        for (size_t i = 0; i < g->ctx.size(); i++) {
+            const int r = G.rank_of_member[i];
+            DeviceScope scope(G.devices[r]);
+            if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+            LUMA_HIP_TRY(hipStreamWaitEvent(G.streams[r], G.rendered[i], 0));
+        }
+        {
+            DeviceScope scope(G.devices[0]);
+            if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+            LUMA_HIP_TRY(hipEventRecord(G.ev_begin, G.streams[0]));
+        }
+        // ... and ONE grouped exchange moves every band into the root: each member sends its band
+        // from its own device (its own xGMI link into the root), the root posts the matching
+        // receives, in member order (sends and receives between one pair of ranks match in order).
+        // Contiguous bands land at their rows of the frame; stripe bands land back to back in the
+        // staging buffer and one kernel puts the stripes in row order.  A member on the root's own
+        // device goes the same way (a send to self inside the group is a local copy).
+        LUMA_RCCL_TRY(rccl, rccl->GroupStart());
+        size_t staged = 0;
+        int rc_group = LUMA_OK;
+        for (size_t i = 0; i < g->ctx.size() && rc_group == LUMA_OK; i++) {
+            luma_ctx* c = g->ctx[i];
+            const int r = G.rank_of_member[i];
+            const size_t count = c->band_pixels();
+            uint32_t* dst = g->striped ? G.staging + staged : frame_dev + static_cast<size_t>(c->row_begin) * width;
+            staged += count;
+            ncclResult_t e;
+            {
+                DeviceScope scope(c->device);
+                if (!scope.ok()) { rc_group = fail(LUMA_E_HIP, who, "hipSetDevice failed"); break; }
+                e = rccl->Send(c->d_target, count, ncclUint32, 0, G.comms[r], G.streams[r]);
+            }
+            if (e == ncclSuccess) {
+                DeviceScope scope(G.devices[0]);
+                if (!scope.ok()) { rc_group = fail(LUMA_E_HIP, who, "hipSetDevice failed"); break; }
+                e = rccl->Recv(dst, count, ncclUint32, r, G.comms[0], G.streams[0]);
+            }
+            if (e != ncclSuccess) { rc_group = fail(LUMA_E_RCCL, "ncclSend/ncclRecv", rccl->GetErrorString(e)); }
+        }
+        const ncclResult_t e_end = rccl->GroupEnd();                  // always closes the group
+        if (rc_group != LUMA_OK) { return rc_group; }
+        if (e_end != ncclSuccess) { return fail(LUMA_E_RCCL, "ncclGroupEnd", rccl->GetErrorString(e_end)); }
+        {
+            DeviceScope scope(G.devices[0]);
+            if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+            if (g->striped) {
+                LUMA_HIP_TRY(luma::launch_deinterleave(G.staging, frame_dev, root->width, root->height, root->stripe,
+                                                       static_cast<uint32_t>(g->ctx.size()), G.streams[0]));
+            }
+            LUMA_HIP_TRY(hipEventRecord(G.ev_end, G.streams[0]));
+        }
+        // synchronous: the frame is complete on return, and no band buffer is still being sent
+        for (size_t r = 0; r < G.devices.size(); r++) {
+            DeviceScope scope(G.devices[r]);
+            if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+            LUMA_HIP_TRY(hipStreamSynchronize(G.streams[r]));
+        }
+        return LUMA_OK;
+    };
+    if (int rc = run()) {
+        for (size_t r = 0; r < G.streams.size(); r++) {               // nothing may still write the caller's frame
+            DeviceScope scope(G.devices[r]);
+            if (scope.ok() && G.streams[r]) { (void)hipStreamSynchronize(G.streams[r]); }
+        }
+        return drain_group_after_error(g, rc);
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        for (luma_ctx* c : g->ctx) {
+            DeviceScope scope(c->device);
+            if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+            luma_stats one{};
+            if (int rc = collect_stats(c, c->stream, &one)) { return rc; }
+            stats->kernel_ms = one.kernel_ms > stats->kernel_ms ? one.kernel_ms : stats->kernel_ms;
+            stats->rays += one.rays;
+            stats->sphere_tests += one.sphere_tests;
+        }
+        DeviceScope scope(G.devices[0]);
+        if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+        float ms = 0.f;
+        LUMA_HIP_TRY(hipEventElapsedTime(&ms, G.ev_begin, G.ev_end));
+        stats->gather_ms = ms;                                        // exchange (+ de-interleave) on the root
         stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return LUMA_OK;

@@ -92,5 +92,9 @@ hipError_t launch_prepare_records(const float* cx, const float* cy, const float*
                                   uint32_t n, const float pos[3], float4* records, hipStream_t stream);
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);
 hipError_t launch_generate_rays(const RenderArgs& args, float* rays, hipStream_t stream);
+// Interleaved-stripe bands gathered back to back in `staging` (member r's compact band, height /
+// n_ranks rows, at r * (height / n_ranks) * width) -> the frame in row order.
+hipError_t launch_deinterleave(const uint32_t* staging, uint32_t* frame, uint32_t width, uint32_t height,
+                               uint32_t stripe, uint32_t n_ranks, hipStream_t stream);
 
 }  // namespace luma

@@ -979,6 +979,22 @@ __global__ void generate_rays_kernel(const RenderArgs A, float* __restrict__ ray
     o[0] = d.x; o[1] = d.y; o[2] = d.z;
 }
 
+// The root's step after the band gather when the frame was cut into interleaved stripes
+// (luma_hip_set_frame_striped): frame row y belongs to rank (y / stripe) % n and is row
+// (y / (stripe * n)) * stripe + y % stripe of that rank's compact band.  One pixel per thread, rows
+// are contiguous on both sides, so loads and stores are coalesced dwords; 8.3 MB each way at 1080p.
+__global__ void deinterleave_kernel(const uint32_t* __restrict__ staging, uint32_t* __restrict__ frame,
+                                    uint32_t width, uint32_t height, uint32_t stripe, uint32_t n_ranks)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t y = blockIdx.y;
+    if (x >= width || y >= height) { return; }
+    const uint32_t chunk = y / stripe, rank = chunk % n_ranks, q = chunk / n_ranks;
+    const uint32_t band_rows = height / n_ranks;
+    const size_t src = ((size_t)rank * band_rows + (size_t)q * stripe + (y % stripe)) * width + x;
+    frame[(size_t)y * width + x] = staging[src];
+}
+
 // How many lanes share one pixel's frames in the ray-per-lane kernel (see SPLIT there): enough to
 // put ~400k threads on the GPU, never more than the frames of the call.
 bool sphere_parallel_scene(uint32_t n_spheres)
@@ -1128,6 +1144,14 @@ hipError_t launch_generate_rays(const RenderArgs& args, float* rays, hipStream_t
     const uint32_t rows = args.rows;
     const dim3 grid((args.width + 255) / 256, rows);
     hipLaunchKernelGGL(generate_rays_kernel, grid, dim3(256), 0, stream, args, rays);
+    return hipGetLastError();
+}
+
+hipError_t launch_deinterleave(const uint32_t* staging, uint32_t* frame, uint32_t width, uint32_t height,
+                               uint32_t stripe, uint32_t n_ranks, hipStream_t stream)
+{
+    const dim3 grid((width + 255) / 256, height);
+    hipLaunchKernelGGL(deinterleave_kernel, grid, dim3(256), 0, stream, staging, frame, width, height, stripe, n_ranks);
     return hipGetLastError();
 }
 

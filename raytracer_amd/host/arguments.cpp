@@ -90,6 +90,10 @@ void Arguments::parse(const std::vector<std::string>& arguments)
             if (ids.empty() || ids.size() > 64) { return false; }
             _options.devices = ids;
             _options.gpus = static_cast<std::uint32_t>(ids.size()); return true; } } },
+        { "gather",  { "gather", [](const std::string& v) {       // how the bands of --gpus N reach `target`
+            if (v == "pcie") { _options.gather_rccl = false; return true; }   // each GPU copies its rows to the host frame
+            if (v == "rccl") { _options.gather_rccl = true; return true; }    // bands gathered on GPU 0 over RCCL, one D2H
+            return false; } } },
         { "seed",    { "seed", [](const std::string& v) {
             std::uint64_t s = 0;
             const bool hex = v.size() > 2 && v[0] == '0' && (v[1] == 'x' || v[1] == 'X');

@@ -1,5 +1,5 @@
 // arguments.h -- luma::Options / luma::Arguments as in the reference (arguments.h:9-49), plus
-// the flags this backend adds: --backend, --gpus, --devices, --seed, --frames, --output, --flags, --shm,
+// the flags this backend adds: --backend, --gpus, --devices, --gather, --seed, --frames, --output, --flags, --shm,
 // --pos/--pitch/--yaw.
 #pragma once
 #include <cstdint>
@@ -23,6 +23,8 @@ struct Options {
     Backend backend = Backend::CPU;
     std::uint32_t gpus = 1;         // devices that share one frame (one process, luma_hip_group_*)
     std::vector<int> devices;       // explicit device ids for them (default 0..gpus-1; an id may repeat)
+    bool gather_rccl = false;       // --gather=rccl: assemble the frame on GPU 0 over RCCL (xGMI), then one copy to the
+                                    // host; default --gather=pcie: every GPU copies its rows into the host frame
     std::uint64_t seed = 0x4C554D41ull;
     std::uint32_t frames = 1;       // headless: frames to accumulate before writing the image
     std::uint32_t flags = 0;        // LUMA_FLAG_* (0 == reference behaviour)

@@ -76,7 +76,11 @@ void Renderer::render_to(std::uint32_t* target, olc::PixelGameEngine* pge) noexc
     p.spp = 1;                                                       // one render_to == one frame
     p.flags = _options.flags;
     p.seed = _options.seed;
-    if (luma_hip_group_render(group_, &p, target, &stats_) != LUMA_OK) { die("luma_hip_group_render"); }   // :392-467
+    if (_options.gather_rccl) {
+        // bands gathered on the root GPU over RCCL, then one D2H copy of the whole frame
+        if (luma_hip_group_render_device(group_, &p, nullptr, &stats_) != LUMA_OK) { die("luma_hip_group_render_device"); }
+        if (luma_hip_group_read_frame(group_, target) != LUMA_OK) { die("luma_hip_group_read_frame"); }
+    } else if (luma_hip_group_render(group_, &p, target, &stats_) != LUMA_OK) { die("luma_hip_group_render"); }   // :392-467
 
     frametime = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - begin).count();   // :469
     frame_count += 1.f;                                              // :470

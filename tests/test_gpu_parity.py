@@ -517,6 +517,87 @@ def test_config3_frame_cut_for_n_gpus_equals_one_gpu(abi, n):
     assert st.rays == wst.rays
 
 
+@pytest.mark.parametrize("W,H,spp,scene_n,flags,what", [
+    (3840, 2160, 256, 0, 0, "config #4"),
+    (7680, 4320, 16, 4096, 0, "config #5"),
+])
+def test_config4_and_config5_as_eight_bands_equal_one_device(abi, W, H, spp, scene_n, flags, what):
+    """BASELINE configs[3] and [4] at full size, cut for 8 GPUs (interleaved 15-row stripes, here all
+    eight bands on one device): the assembled frame and the accumulation buffer equal the one-context
+    render bit for bit, as test_config3_frame_cut_for_n_gpus_equals_one_gpu shows for config #3."""
+    scene = abi.synthetic_scene(scene_n) if scene_n else abi.default_scene()
+    params = abi.make_params(W, H, spp=spp, bounces=5, paths=1, samples=1, mode=1, flags=flags, seed=SEED)
+    with abi.Context(0) as ctx:
+        ctx.set_scene(scene); ctx.set_camera(abi.default_camera(W, H)); ctx.set_frame(W, H)
+        want, wst = ctx.render(params)
+        wacc = ctx.read_accum()
+    with abi.Group([0] * 8) as g:
+        g.set_scene(scene); g.set_camera(abi.default_camera(W, H)); g.set_frame(W, H)
+        got, st = g.render(params)
+        assert_frames_equal(got, want, f"{what} in 8 bands")
+        del got
+        acc = g.read_accum()
+    assert np.array_equal(acc.view(np.uint32), wacc.view(np.uint32))
+    assert st.rays == wst.rays
+
+
+def test_config5_band_through_the_grid_equals_the_linear_band(abi):
+    """One of config #5's eight stripe bands (7680x540, 16 spp, 4096 spheres) with LUMA_FLAG_GRID
+    against the same band scanned linearly."""
+    W, H = 7680, 4320
+    scene = abi.synthetic_scene(4096)
+    out = []
+    for flags in (0, abi.FLAG_GRID):
+        with abi.Context(0) as ctx:
+            ctx.set_scene(scene); ctx.set_camera(abi.default_camera(W, H)); ctx.set_frame_striped(W, H, 15, 3, 8)
+            img, st = ctx.render(abi.make_params(W, H, spp=16, bounces=5, paths=1, samples=1, mode=1, flags=flags, seed=SEED))
+            out.append((img, ctx.read_accum(), st.rays))
+    assert_frames_equal(out[1][0], out[0][0], "config #5 band, grid against linear")
+    assert np.array_equal(out[1][1].view(np.uint32), out[0][1].view(np.uint32))
+    assert out[1][2] == out[0][2]
+
+
+# ---- bands gathered on the root GPU over RCCL -----------------------------
+
+@pytest.mark.parametrize("W,H,ids,scene_n", [
+    (64, 36, [0], 0),             # one device, one band: a 1-rank communicator, send to self
+    (96, 60, [0, 0], 0),          # interleaved stripes -> staging buffer + de-interleave kernel
+    (70, 53, [0, 0, 0], 0),       # ragged contiguous bands received straight into the frame
+    (1920, 1080, [0] * 8, 0),     # config #3's frame cut for 8 GPUs (8.3 MB through the exchange)
+    (48, 120, [0] * 8, 384),      # sphere-parallel kernel, stripes
+])
+def test_group_render_device_gathers_over_rccl(abi, W, H, ids, scene_n):
+    """luma_hip_group_render_device: the members' bands reach the root GPU through ONE grouped
+    ncclSend/ncclRecv exchange on a communicator over the group's distinct devices (here device 0
+    alone, so every band is a send to self), into the caller's device frame or the group's own.
+    Frame, accumulators and ray count equal the one-context luma_hip_render_device, two calls in a
+    row (progressive accumulation), and gather_ms is reported."""
+    kw = dict(spp=3, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    scene = abi.synthetic_scene(scene_n) if scene_n else abi.default_scene()
+    params = abi.make_params(W, H, **kw)
+    with abi.Context(0) as ctx, abi.Group(ids) as g:
+        ctx.set_scene(scene); ctx.set_camera(abi.default_camera(W, H)); ctx.set_frame(W, H)
+        g.set_scene(scene); g.set_camera(abi.default_camera(W, H)); g.set_frame(W, H)
+        with abi.Context(0) as holder:                      # a caller-owned device frame: another context's buffer
+            holder.set_scene(scene); holder.set_camera(abi.default_camera(W, H)); holder.set_frame(W, H)
+            for call in range(2):
+                wst = ctx.render_device(params, want_stats=True)
+                want, wacc = ctx.read_target(), ctx.read_accum()
+                if call == 0:
+                    st = g.render_device(params)            # the group's own frame
+                    got = g.read_frame()
+                    assert g.frame_device()
+                else:
+                    st = g.render_device(params, holder.target_device())
+                    got = holder.read_target()
+                assert_frames_equal(got, want, f"RCCL-gathered frame, {len(ids)} band(s), call {call}")
+                assert np.array_equal(g.read_accum().view(np.uint32), wacc.view(np.uint32))
+                assert st.rays == wst.rays and st.kernel_ms > 0 and st.gather_ms > 0
+        with pytest.raises(abi.LumaError) as e:             # host memory is not a device frame
+            g.render_device(params, np.zeros((H, W), np.uint32).ctypes.data)
+        assert e.value.code == abi.E_ARG
+
+
 def test_render_frame_scatters_bands_into_one_frame(abi):
     """luma_hip_render_frame: each context writes only its own rows of the shared host frame."""
     W, H, n = 80, 90, 3

@@ -88,6 +88,42 @@ def test_headless_several_devices_one_frame(tmp_path, oracle, sel, H):
 
 
 @pytest.mark.gpu
+def test_headless_config1_writes_the_full_size_ppm(tmp_path, oracle):
+    """BASELINE configs[0] end to end: default scene, 1280x720, 1 spp, direct shading (raytrace, one
+    bounce), written as output.ppm by Image::export_to_ppm (image.cpp:30-64) -- every byte of the
+    22 MB P3 file equals the oracle's frame through the oracle's writer."""
+    W, H = 1280, 720
+    out = tmp_path / "output.ppm"
+    r = run("--backend", "hip", f"--width={W}", f"--height={H}", "--mode=raytrace", "--samples=1", "--bounces=1",
+            "--frames=1", f"--output={out}")
+    assert r.returncode == 0, r.stdout + r.stderr
+    want, _, _ = oracle.render(oracle.default_scene(), oracle.camera(W, H),
+                               oracle.make_params(W, H, seed=0x4C554D41, spp=1, bounces=1, mode=0, flags=0))
+    ref = tmp_path / "oracle.ppm"
+    assert oracle.export_ppm(want, str(ref)) == 0
+    got, exp = out.read_bytes(), ref.read_bytes()
+    assert got[:16] == b"P3\n1280 720\n255\n"
+    assert got == exp
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("sel,H", [("--devices=0", 54), ("--devices=0,0", 60), ("--devices=0,0,0", 54)])
+def test_headless_gather_over_rccl(tmp_path, oracle, sel, H):
+    """--gather=rccl: the bands are gathered on the first device over RCCL
+    (luma_hip_group_render_device) and the frame comes to the host in one copy; same PPM."""
+    W = 96
+    out = tmp_path / "frame.ppm"
+    r = run("--backend", "hip", sel, "--gather=rccl", f"--width={W}", f"--height={H}", "--mode=pathtrace", "--bounces=5",
+            "--samples=1", "--paths=1", "--frames=3", f"--output={out}")
+    assert r.returncode == 0, r.stdout + r.stderr
+    want, _, _ = oracle.render(oracle.default_scene(), oracle.camera(W, H),
+                               oracle.make_params(W, H, seed=0x4C554D41, spp=3, bounces=5, mode=1, flags=0))
+    ref = tmp_path / "oracle.ppm"
+    assert oracle.export_ppm(want, str(ref)) == 0
+    assert out.read_bytes() == ref.read_bytes()
+
+
+@pytest.mark.gpu
 def test_headless_posed_camera(tmp_path, oracle):
     """--pos/--pitch/--yaw go through Camera::move_to -> update -> the camera.moved branch
     (Renderer.cpp:377-390) before the first frame."""
