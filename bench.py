@@ -223,6 +223,7 @@ def main():
         ctx.set_frame_striped(WIDTH, HEIGHT, stripe, rb, nb)
     else:
         ctx.set_frame(WIDTH, HEIGHT, y0, y1)
+    ctx.reserve(SPP)                               # set-up: no allocation inside the timed render calls
     params = abi.make_params(WIDTH, HEIGHT, spp=SPP, bounces=BOUNCES, paths=PATHS, samples=SAMPLES,
                              mode=wl["mode"], flags=wl["flags"] | (abi.FLAG_GRID if a.grid else 0), seed=SEED)
     stream = torch.cuda.Stream(device=dev)          # a real (non-null) stream: kernels, gather and events share it

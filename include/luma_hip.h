@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define LUMA_HIP_ABI_VERSION 1
+#define LUMA_HIP_ABI_VERSION 2   /* 2: luma_stats gained lanes_per_pixel / split_refused */
 
 enum {
     LUMA_OK       = 0,
@@ -90,6 +90,12 @@ typedef struct {
      * they ran against); the times are those of this call alone. */
     uint64_t rays;          /* trace_ray invocations executed (Renderer.cpp:234) */
     uint64_t sphere_tests;  /* ray-sphere tests executed (loop at Renderer.cpp:242) */
+    /* How the latest launch used the GPU (no counterpart in the reference): lanes that shared one
+     * pixel's frames (1, 2 or 4; small bands of small scenes use several), and 1 in
+     * split_refused when it ran one lane per pixel only because the planes in which the extra lanes
+     * park their frames (spp * 12 B * band pixels) would have passed 2 GiB. */
+    uint32_t lanes_per_pixel;
+    uint32_t split_refused;
 } luma_stats;
 
 /* ---- lifetime ------------------------------------------------------------------ */
@@ -123,6 +129,17 @@ int luma_hip_set_frame(luma_ctx* ctx, uint32_t width, uint32_t height,
  * the frame is still bit-identical to a one-device render.  No counterpart in the reference. */
 int luma_hip_set_frame_striped(luma_ctx* ctx, uint32_t width, uint32_t height, uint32_t stripe_rows,
                                uint32_t rank, uint32_t n_ranks);
+
+/* Set-up for render calls of up to max_spp frames on the current scene and frame: allocates now
+ * whatever device scratch such calls use (the planes in which small bands park frames rendered by
+ * several lanes of one pixel), so that luma_hip_render* itself never allocates or synchronises the
+ * device for it.  Optional: without it the first render call that needs more scratch than the
+ * context holds allocates it.  Call again after luma_hip_set_frame* / luma_hip_set_scene.
+ * luma_hip_alloc_count reports how many device allocations render calls have made on the context
+ * since luma_hip_create (0 after a luma_hip_reserve that covers them; LUMA_FLAG_GRID adds 3 per
+ * scene for its tables).  No counterpart in the reference. */
+int luma_hip_reserve(luma_ctx* ctx, uint32_t max_spp);
+int luma_hip_alloc_count(luma_ctx* ctx, uint64_t* count);
 
 /* The camera.moved branch, Renderer.cpp:377-390: frame_count = 1, accumulated_data = 0. */
 int luma_hip_reset(luma_ctx* ctx);
@@ -196,6 +213,7 @@ int  luma_hip_group_set_scene(luma_group* g, const luma_sphere* spheres, uint32_
 int  luma_hip_group_set_camera(luma_group* g, const luma_camera* cam);
 int  luma_hip_group_set_frame(luma_group* g, uint32_t width, uint32_t height);
 int  luma_hip_group_reset(luma_group* g);
+int  luma_hip_group_reserve(luma_group* g, uint32_t max_spp);        /* luma_hip_reserve on every member */
 /* Renderer::render_to over the whole frame: frame_host receives width*height pixels.  kernel_ms is
  * the slowest device's, rays / sphere_tests are summed.  After a failure call luma_hip_group_reset
  * (devices may have advanced unevenly). */

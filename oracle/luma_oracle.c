@@ -14,7 +14,24 @@
 #include <stdlib.h>
 #include <string.h>
 
+/* Two builds of this file (oracle/Makefile):
+ *   default      the arithmetic CONTRACT the HIP kernels share: every multiply-add written FMA()
+ *                below is one fused operation, normalize multiplies by 1/sqrt, exp and the DOF
+ *                term are fixed float evaluations.  libluma_oracle.so, the parity checker.
+ *   -DLO_LITERAL the reference's expressions taken literally, with none of those choices: no
+ *                fusion anywhere (a*b+c is two roundings), normalize divides by sqrtf, tonemap
+ *                calls libm expf (std::exp(float), Renderer.cpp:61), and the DOF term runs in
+ *                double exactly as Renderer.cpp:427-432 writes it (std::pow / std::exp /
+ *                std::lerp on promoted operands, `focus < .5f` compared in double).
+ *                libluma_oracle_literal.so: only tests/golden/make_contract_sensitivity.py and
+ *                tests/test_contract_sensitivity.py load it, to MEASURE how far frames move when
+ *                the contract's choices flip (the reference is built /fp:fast, which leaves them
+ *                open: raytracer.vcxproj:187-190). */
+#ifdef LO_LITERAL
+#define FMA(a, b, c) ((a) * (b) + (c))
+#else
 #define FMA(a, b, c) fmaf((a), (b), (c))
+#endif
 
 typedef struct { float x, y, z; } v3;
 
@@ -29,7 +46,11 @@ static v3 v3_neg(v3 a) { return v3_make(-a.x, -a.y, -a.z); }                 /* 
 /* fx::dot: x first, then y and z folded in with one rounding each. */
 static float v3_dot(v3 a, v3 b) { return FMA(a.z, b.z, FMA(a.y, b.y, a.x * b.x)); }
 /* fx::normalize: v * (1 / sqrt(dot(v,v))). */
+#ifdef LO_LITERAL
+static v3 v3_normalize(v3 a) { float len = sqrtf(v3_dot(a, a)); return v3_make(a.x / len, a.y / len, a.z / len); }
+#else
 static v3 v3_normalize(v3 a) { float inv = 1.0f / sqrtf(v3_dot(a, a)); return v3_scale(a, inv); }
+#endif
 /* fx::reflect(d, n) = d - 2*dot(d,n)*n, one rounding per component. */
 static v3 v3_reflect(v3 d, v3 n)
 {
@@ -51,6 +72,9 @@ static v3 v3_cross(v3 a, v3 b)
  * ------------------------------------------------------------------------------- */
 float lo_expf(float x)
 {
+#ifdef LO_LITERAL
+    return expf(x);
+#endif
     if (!(x >= -87.0f)) { return (x != x) ? x : 0.0f; }
     if (x > 88.0f) { return INFINITY; }
     float kf = rintf(x * 1.44269504088896341f);
@@ -181,8 +205,33 @@ static v3 color_lerp(v3 c1, v3 c2, float t)
  * 1 - exp(-pow(dd, 10)) and std::lerp(.5, 5, focus) in double; the contract restates
  * them in float (dd^10 by four multiplies, lo_expf) so that CPU and GPU agree bit for
  * bit.  The deviation from the double evaluation is bounded in tests/test_oracle_kat.py. */
+/* *in_focus_out = the `focus < .5f` decision of Renderer.cpp:450 (taken in double in the reference
+ * because `focus` is a double there). */
+static float focus_term(float depth, float focus_depth, float* blur_out, int* in_focus_out)
+{
+#ifdef LO_LITERAL
+    const float depth_difference = depth - focus_depth;                       /* :425 */
+    const double focus = 1.f - exp(-pow((double)depth_difference, 10));       /* :427 */
+    const double a = .5f, b = 5.f;
+    /* std::lerp(a, b, t) for finite a, b of the same sign: a + t * (b - a), exact at t == 1 */
+    const double blur = (focus == 1.0) ? b : a + focus * (b - a);             /* :432 */
+    if (blur_out) { *blur_out = (float)blur; }                                /* :434 static_cast */
+    if (in_focus_out) { *in_focus_out = focus < .5f; }                        /* :450 */
+    return (float)focus;
+#else
+    float blur;
+    const float focus = lo_focus(depth, focus_depth, &blur);
+    if (blur_out) { *blur_out = blur; }
+    if (in_focus_out) { *in_focus_out = focus < .5f; }
+    return focus;
+#endif
+}
+
 float lo_focus(float depth, float focus_depth, float* blur_out)
 {
+#ifdef LO_LITERAL
+    return focus_term(depth, focus_depth, blur_out, NULL);
+#endif
     float dd = depth - focus_depth;
     float x2 = dd * dd;
     float x4 = x2 * x2;
@@ -621,11 +670,12 @@ void lo_render(const lo_sphere* spheres, uint32_t n_spheres, const lo_camera* ca
                 if (is.object >= 0) { depth = is.distance; }
 
                 float blur;
-                float focus = lo_focus(depth, cam->focus_depth, &blur); /* :425-432 */
+                int in_focus;
+                focus_term(depth, cam->focus_depth, &blur, &in_focus); /* :425-432 */
 
                 v3 result = render_pixel(&f, dir, index, sample, blur); /* :434-435 */
 
-                if (show_depth && focus < .5f) {                     /* :448-454 */
+                if (show_depth && in_focus) {                        /* :448-454 */
                     result = v3_scale(result, 1.2f);
                 }
 
@@ -639,6 +689,29 @@ void lo_render(const lo_sphere* spheres, uint32_t n_spheres, const lo_camera* ca
         }
     }
     free(rays);
+}
+
+/* The DOF pre-pass alone (Renderer.cpp:413-432) for rows [row_begin,row_end): per pixel the blur
+ * handed to render_pixel and the `focus < .5f` decision.  For tests/golden/make_contract_sensitivity.py,
+ * which counts the pixels whose decision differs between the two builds of this file. */
+void lo_dof_prepass(const lo_sphere* spheres, uint32_t n_spheres, const lo_camera* cam,
+                    uint32_t width, uint32_t height, uint32_t row_begin, uint32_t row_end,
+                    float* blur, uint8_t* in_focus)
+{
+    scene_t sc = { spheres, n_spheres, NULL };
+    const v3 campos = v3_make(cam->pos[0], cam->pos[1], cam->pos[2]);
+    if (row_end > height) { row_end = height; }
+    for (uint32_t y = row_begin; y < row_end; y++) {
+        for (uint32_t x = 0; x < width; x++) {
+            const size_t index = (size_t)y * width + x;
+            isect_t is = trace_ray(&sc, campos, camera_ray(cam, x, y, width, height));   /* :418 */
+            float depth = FLT_MAX;
+            if (is.object >= 0) { depth = is.distance; }
+            int flag;
+            focus_term(depth, cam->focus_depth, &blur[index], &flag);
+            in_focus[index] = (uint8_t)flag;
+        }
+    }
 }
 
 /* ---------------------------------------------------------------------------------

@@ -30,6 +30,7 @@ SYMBOLS = [
     "luma_hip_host_alloc", "luma_hip_host_free", "luma_grid_describe", "luma_hip_read_target",
     "luma_hip_render_device_noalloc",
     "luma_hip_group_render_device", "luma_hip_group_frame_device", "luma_hip_group_read_frame",
+    "luma_hip_reserve", "luma_hip_alloc_count", "luma_hip_group_reserve",
 ]
 
 
@@ -57,7 +58,8 @@ class GridInfo(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("gather_ms", C.c_double), ("total_ms", C.c_double),
-                ("rays", C.c_uint64), ("sphere_tests", C.c_uint64)]
+                ("rays", C.c_uint64), ("sphere_tests", C.c_uint64),
+                ("lanes_per_pixel", C.c_uint32), ("split_refused", C.c_uint32)]
 
 
 class LumaError(RuntimeError):
@@ -89,6 +91,8 @@ def lib():
         "luma_hip_set_frame": (C.c_int, [ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
         "luma_hip_set_frame_striped": (C.c_int, [ctx, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
         "luma_hip_reset": (C.c_int, [ctx]),
+        "luma_hip_reserve": (C.c_int, [ctx, C.c_uint32]),
+        "luma_hip_alloc_count": (C.c_int, [ctx, C.POINTER(C.c_uint64)]),
         "luma_hip_render": (C.c_int, [ctx, C.POINTER(Params), u32p, C.POINTER(Stats)]),
         "luma_hip_render_device": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
         "luma_hip_render_device_noalloc": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.c_void_p]),
@@ -112,6 +116,7 @@ def lib():
         "luma_hip_group_set_camera": (C.c_int, [ctx, C.POINTER(Camera)]),
         "luma_hip_group_set_frame": (C.c_int, [ctx, C.c_uint32, C.c_uint32]),
         "luma_hip_group_reset": (C.c_int, [ctx]),
+        "luma_hip_group_reserve": (C.c_int, [ctx, C.c_uint32]),
         "luma_hip_group_render": (C.c_int, [ctx, C.POINTER(Params), u32p, C.POINTER(Stats)]),
         "luma_hip_group_read_accum": (C.c_int, [ctx, f32p]),
         "luma_hip_group_render_device": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]),
@@ -273,6 +278,14 @@ class Context:
     def reset(self):
         check(lib().luma_hip_reset(self._h), "luma_hip_reset")
 
+    def reserve(self, max_spp):
+        check(lib().luma_hip_reserve(self._h, max_spp), "luma_hip_reserve")
+
+    def alloc_count(self):
+        n = C.c_uint64()
+        check(lib().luma_hip_alloc_count(self._h, C.byref(n)), "luma_hip_alloc_count")
+        return n.value
+
     @property
     def rows(self):
         return self.row_end - self.row_begin
@@ -370,6 +383,9 @@ class Group:
 
     def reset(self):
         check(lib().luma_hip_group_reset(self._h), "luma_hip_group_reset")
+
+    def reserve(self, max_spp):
+        check(lib().luma_hip_group_reserve(self._h, max_spp), "luma_hip_group_reserve")
 
     def read_accum(self):
         out = np.empty((self.height, self.width, 3), dtype=np.float32)

@@ -97,8 +97,11 @@ struct luma_ctx {
     bool have_frame = false;
     hipStream_t last_stream = nullptr;   // stream of the latest render call (the planes are RMW state)
     bool rendered = false;
-    float* d_split = nullptr;      // parked frames of split renders (luma_kernels.hip, SPLIT), grown on demand
-    size_t split_bytes = 0;
+    float* d_split = nullptr;      // parked frames of split renders (luma_kernels.hip, SPLIT): sized by luma_hip_reserve,
+    size_t split_bytes = 0;        //   else grown by the first call that needs more
+    uint64_t device_allocs = 0;    // hipMalloc calls made by render calls (luma_hip_alloc_count)
+    uint32_t last_split = 1;       // lanes per pixel of the latest launch, and whether it wanted more lanes
+    bool last_split_refused = false;   //   than the 2 GiB cap on the parking planes allowed
 
     unsigned char* static_scratch = nullptr;   // this device's copy of luma_kernels.hip's `scratch` (render_device_noalloc)
 
@@ -220,6 +223,7 @@ int refresh_grid(luma_ctx* ctx)
     LUMA_HIP_TRY(upload(ctx->d_grid_cells, g.cell_start));
     LUMA_HIP_TRY(upload(ctx->d_grid_items, g.items));
     LUMA_HIP_TRY(upload(ctx->d_grid_large, g.large));
+    ctx->device_allocs += 3;
     luma::GridArgs& a = ctx->grid;
     for (int i = 0; i < 3; i++) { a.dims[i] = g.dims[i]; a.org[i] = g.org[i]; }
     a.h = g.h;
@@ -240,6 +244,24 @@ int order_after_previous(luma_ctx* ctx, hipStream_t stream)
     return LUMA_OK;
 }
 
+constexpr size_t kMaxSplitBytes = size_t(2) << 30;
+
+size_t split_parking_bytes(const luma_ctx* ctx, uint32_t spp)
+{
+    return static_cast<size_t>(spp) * 3u * ctx->band_pixels() * sizeof(float);   // a slot per frame
+}
+
+int grow_split_planes(luma_ctx* ctx, size_t need)
+{
+    LUMA_HIP_TRY(hipDeviceSynchronize());
+    free_dev(ctx->d_split);
+    ctx->split_bytes = 0;
+    LUMA_HIP_TRY(hipMalloc(&ctx->d_split, need));
+    ctx->device_allocs++;
+    ctx->split_bytes = need;
+    return LUMA_OK;
+}
+
 // Enqueue one render call on `stream`.  With `timed`, events bracket the render kernel only.
 int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hipStream_t stream, bool timed)
 {
@@ -249,19 +271,19 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
     if (grid) { if (int rc = refresh_grid(ctx)) { return rc; } }
     luma::RenderArgs args = make_args(ctx, p, target_dev);
     args.split = luma::choose_split(ctx->band_pixels(), p->spp, ctx->n_spheres, grid);
+    ctx->last_split_refused = false;
     if (args.split > 1) {
-        const size_t need = static_cast<size_t>(p->spp) * 3u * ctx->band_pixels() * sizeof(float);   // a slot per frame
-        if (need > (size_t(2) << 30)) {
-            args.split = 1;                                      // not worth 2 GiB of scratch
+        const size_t need = split_parking_bytes(ctx, p->spp);
+        if (need > kMaxSplitBytes) {
+            args.split = 1;                                      // not worth 2 GiB of scratch; reported in luma_stats
+            ctx->last_split_refused = true;
         } else if (need > ctx->split_bytes) {
-            LUMA_HIP_TRY(hipDeviceSynchronize());
-            free_dev(ctx->d_split);
-            ctx->split_bytes = 0;
-            LUMA_HIP_TRY(hipMalloc(&ctx->d_split, need));
-            ctx->split_bytes = need;
+            // only when luma_hip_reserve was not called (or named fewer spp): the first such call pays
+            if (int rc = grow_split_planes(ctx, need)) { return rc; }
         }
         args.split_scratch = ctx->d_split;
     }
+    ctx->last_split = args.split;
     if (!grid && luma::sphere_parallel_scene(ctx->n_spheres)) {
         LUMA_HIP_TRY(hipMemsetAsync(args.tile_counter, 0, sizeof(uint32_t), stream));
     }
@@ -305,6 +327,8 @@ int collect_stats(luma_ctx* ctx, hipStream_t stream, luma_stats* stats)
     float ms = 0.f;
     LUMA_HIP_TRY(hipEventElapsedTime(&ms, ctx->ev_begin, ctx->ev_end));
     stats->kernel_ms = ms;
+    stats->lanes_per_pixel = ctx->last_split;
+    stats->split_refused = ctx->last_split_refused ? 1u : 0u;
     stats->rays = ctx->rays_pending;            // since the previous luma_stats
     stats->sphere_tests = ctx->tests_pending;
     ctx->rays_pending = ctx->tests_pending = 0;
@@ -590,6 +614,28 @@ int luma_hip_reset(luma_ctx* ctx)
     return LUMA_OK;
 }
 
+int luma_hip_reserve(luma_ctx* ctx, uint32_t max_spp)
+{
+    const char* who = "luma_hip_reserve";
+    if (!ctx) { return fail(LUMA_E_ARG, who, "null context"); }
+    if (!ctx->have_frame || !ctx->have_scene) { return fail(LUMA_E_STATE, who, "scene and frame must be set"); }
+    if (max_spp == 0) { return fail(LUMA_E_ARG, who, "max_spp must be >= 1"); }
+    DeviceScope scope(ctx->device);
+    if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+    // the largest need over spp = 1 .. max_spp is at max_spp whenever frames are split at all
+    const uint32_t split = luma::choose_split(ctx->band_pixels(), max_spp, ctx->n_spheres, false);
+    const size_t need = split > 1 ? split_parking_bytes(ctx, max_spp) : 0;
+    if (need > kMaxSplitBytes || need <= ctx->split_bytes) { return LUMA_OK; }   // over the cap: such calls run one lane per pixel
+    return grow_split_planes(ctx, need);
+}
+
+int luma_hip_alloc_count(luma_ctx* ctx, uint64_t* count)
+{
+    if (!ctx || !count) { return fail(LUMA_E_ARG, "luma_hip_alloc_count", "null argument"); }
+    *count = ctx->device_allocs;
+    return LUMA_OK;
+}
+
 int luma_hip_render(luma_ctx* ctx, const luma_params* params, uint32_t* target_host, luma_stats* stats)
 {
     if (int rc = check_params(ctx, params)) { return rc; }
@@ -836,6 +882,13 @@ int luma_hip_group_set_frame(luma_group* g, uint32_t width, uint32_t height)
     return LUMA_OK;
 }
 
+int luma_hip_group_reserve(luma_group* g, uint32_t max_spp)
+{
+    if (!g) { return fail(LUMA_E_ARG, "luma_hip_group_reserve", "null group"); }
+    for (luma_ctx* c : g->ctx) { if (int rc = luma_hip_reserve(c, max_spp)) { return rc; } }
+    return LUMA_OK;
+}
+
 int luma_hip_group_reset(luma_group* g)
 {
     if (!g) { return fail(LUMA_E_ARG, "luma_hip_group_reset", "null group"); }
@@ -908,6 +961,8 @@ int luma_hip_group_render(luma_group* g, const luma_params* params, uint32_t* fr
             luma_stats one{};
             if (int rc = collect_stats(c, c->stream, &one)) { return rc; }
             stats->kernel_ms = one.kernel_ms > stats->kernel_ms ? one.kernel_ms : stats->kernel_ms;
+            stats->lanes_per_pixel = one.lanes_per_pixel > stats->lanes_per_pixel ? one.lanes_per_pixel : stats->lanes_per_pixel;
+            stats->split_refused |= one.split_refused;
             stats->rays += one.rays;
             stats->sphere_tests += one.sphere_tests;
         }
@@ -1115,6 +1170,8 @@ int luma_hip_group_render_device(luma_group* g, const luma_params* params, uint3
             luma_stats one{};
             if (int rc = collect_stats(c, c->stream, &one)) { return rc; }
             stats->kernel_ms = one.kernel_ms > stats->kernel_ms ? one.kernel_ms : stats->kernel_ms;
+            stats->lanes_per_pixel = one.lanes_per_pixel > stats->lanes_per_pixel ? one.lanes_per_pixel : stats->lanes_per_pixel;
+            stats->split_refused |= one.split_refused;
             stats->rays += one.rays;
             stats->sphere_tests += one.sphere_tests;
         }

@@ -12,6 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "libluma_oracle.so")
+LITERAL_SO = os.path.join(ORACLE_DIR, "libluma_oracle_literal.so")   # -DLO_LITERAL build: sensitivity study only
 
 FLAG_NOISE_OFF = 1
 FLAG_ORIGIN_FROM_HIT = 2
@@ -47,21 +48,36 @@ def build(force=False):
     """Compile the oracle with oracle/Makefile if the .so is missing or stale."""
     src = os.path.join(ORACLE_DIR, "luma_oracle.c")
     hdr = os.path.join(ORACLE_DIR, "luma_oracle.h")
-    stale = (not os.path.exists(ORACLE_SO)
-             or (os.path.exists(src) and os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr))))
+    stale = any(not os.path.exists(so)
+                or (os.path.exists(src) and os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)))
+                for so in (ORACLE_SO, LITERAL_SO) if so.startswith(ORACLE_DIR))
     if force or stale:
         subprocess.check_call(["make", "-s", "-C", ORACLE_DIR] + (["-B"] if force else []))
 
 
 _lib = None
+_literal = None
 
 
 def lib():
     global _lib
-    if _lib is not None:
-        return _lib
-    build()
-    L = C.CDLL(ORACLE_SO)
+    if _lib is None:
+        build()
+        _lib = _bind(C.CDLL(ORACLE_SO))
+    return _lib
+
+
+def literal_lib():
+    """The -DLO_LITERAL build of the oracle (no fusion, double DOF term, libm expf).  NOT the parity
+    checker: it exists to measure how far frames move when the arithmetic contract's choices flip."""
+    global _literal
+    if _literal is None:
+        build()
+        _literal = _bind(C.CDLL(LITERAL_SO))
+    return _literal
+
+
+def _bind(L):
     f32p = C.POINTER(C.c_float)
     u32p = C.POINTER(C.c_uint32)
     L.lo_expf.restype = C.c_float
@@ -90,7 +106,8 @@ def lib():
     L.lo_export_ppm.argtypes = [u32p, C.c_int32, C.c_int32, C.c_char_p]
     L.lo_export_bmp.restype = C.c_int
     L.lo_export_bmp.argtypes = [u32p, C.c_int32, C.c_int32, C.c_char_p]
-    _lib = L
+    L.lo_dof_prepass.argtypes = [C.POINTER(Sphere), C.c_uint32, C.POINTER(Camera), C.c_uint32, C.c_uint32,
+                                 C.c_uint32, C.c_uint32, f32p, C.POINTER(C.c_uint8)]
     return L
 
 
@@ -142,7 +159,8 @@ class Renderer:
     """Holds the reference's accumulated_data / frame_count across render calls
     (renderer.h:52-56) and renders with the oracle."""
 
-    def __init__(self, spheres, cam, width, height):
+    def __init__(self, spheres, cam, width, height, L=None):
+        self.L = L or lib()
         self.spheres = spheres
         self.cam = cam
         self.width, self.height = width, height
@@ -156,7 +174,7 @@ class Renderer:
 
     def render(self, params, rows=None):
         y0, y1 = rows if rows is not None else (0, self.height)
-        lib().lo_render(self.spheres, len(self.spheres), C.byref(self.cam), C.byref(params), self.frame_index,
+        self.L.lo_render(self.spheres, len(self.spheres), C.byref(self.cam), C.byref(params), self.frame_index,
                         y0, y1, _f32p(self.accum), _u32p(self.target), C.byref(self.stats))
         if rows is None:
             self.frame_index += params.spp
@@ -167,6 +185,16 @@ def render(spheres, cam, params, rows=None):
     r = Renderer(spheres, cam, params.width, params.height)
     r.render(params, rows)
     return r.target, r.accum, r.stats
+
+
+def dof_prepass(spheres, cam, width, height, rows=None, L=None):
+    """(blur float32 [H,W], in_focus uint8 [H,W]) of the DOF pre-pass for the rows."""
+    y0, y1 = rows if rows is not None else (0, height)
+    blur = np.zeros((height, width), dtype=np.float32)
+    flag = np.zeros((height, width), dtype=np.uint8)
+    (L or lib()).lo_dof_prepass(spheres, len(spheres), C.byref(cam), width, height, y0, y1, _f32p(blur),
+                                flag.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return blur, flag
 
 
 def export_ppm(target, path):

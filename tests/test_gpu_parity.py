@@ -557,6 +557,42 @@ def test_config5_band_through_the_grid_equals_the_linear_band(abi):
     assert out[1][2] == out[0][2]
 
 
+def test_reserve_takes_allocation_out_of_the_render_call(abi):
+    """One of config #3's eight bands (4 lanes per pixel, 199 MB of parking planes at 64 spp).
+    Without luma_hip_reserve the first render call allocates the planes and the second does not;
+    with it no render call allocates at all.  Same frames either way.  A call whose planes would
+    pass 2 GiB runs one lane per pixel and says so in luma_stats."""
+    W, H = 1920, 1080
+    params = abi.make_params(W, H, spp=64, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    frames = []
+    for reserve in (False, True):
+        with abi.Context(0) as ctx:
+            ctx.set_scene(abi.default_scene()); ctx.set_camera(abi.default_camera(W, H))
+            ctx.set_frame_striped(W, H, 15, 2, 8)
+            if reserve:
+                ctx.reserve(64)
+            assert ctx.alloc_count() == 0
+            st = ctx.render_device(params, want_stats=True)
+            assert st.lanes_per_pixel == 4 and st.split_refused == 0
+            first = ctx.alloc_count()
+            assert first == (0 if reserve else 1)
+            ctx.render_device(params)
+            ctx.render_device(abi.make_params(W, H, spp=16, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED))
+            assert ctx.alloc_count() == first                       # context-warm calls never allocate
+            frames.append((ctx.read_target(), ctx.read_accum()))
+    assert_frames_equal(frames[1][0], frames[0][0], "reserved against grown on demand")
+    assert np.array_equal(frames[1][1].view(np.uint32), frames[0][1].view(np.uint32))
+    # 1.04 M pixels x 256 spp would park 3.2 GB: refused, reported, still the right frame (config #4's band)
+    W, H = 3840, 2160
+    big = abi.make_params(W, H, spp=256, bounces=1, paths=1, samples=1, mode=0, flags=0, seed=SEED)
+    with abi.Context(0) as ctx:
+        ctx.set_scene(abi.default_scene()); ctx.set_camera(abi.default_camera(W, H))
+        ctx.set_frame_striped(W, H, 15, 0, 8)
+        ctx.reserve(256)
+        st = ctx.render_device(big, want_stats=True)
+        assert st.lanes_per_pixel == 1 and st.split_refused == 1 and ctx.alloc_count() == 0
+
+
 # ---- bands gathered on the root GPU over RCCL (SURVEY 8e) -----------------------------
 
 @pytest.mark.parametrize("W,H,ids,scene_n", [
