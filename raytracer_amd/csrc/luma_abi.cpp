@@ -257,7 +257,6 @@ int grow_split_planes(luma_ctx* ctx, size_t need)
     free_dev(ctx->d_split);
     ctx->split_bytes = 0;
     LUMA_HIP_TRY(hipMalloc(&ctx->d_split, need));
-    ctx->device_allocs++;
     ctx->split_bytes = need;
     return LUMA_OK;
 }
@@ -280,6 +279,7 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
         } else if (need > ctx->split_bytes) {
             // only when luma_hip_reserve was not called (or named fewer spp): the first such call pays
             if (int rc = grow_split_planes(ctx, need)) { return rc; }
+            ctx->device_allocs++;
         }
         args.split_scratch = ctx->d_split;
     }

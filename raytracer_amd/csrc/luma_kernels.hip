@@ -36,23 +36,43 @@ LUMA_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 LUMA_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 LUMA_DEV float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 
-// Correctly rounded sqrt.  hipcc's sqrtf() expansion spends 6 of its 17 VALU instructions on
-// rescaling tiny inputs and on the 0/inf class check; for 2^-96 <= x < 2^96 (every
-// discriminant and squared length on the path) the core of that expansion alone is exact:
-// v_sqrt_f32 is within 1 ulp, and the two residuals pick the neighbour when it is closer.
+// Correctly rounded sqrt and reciprocal, short forms.  The oracle calls libm sqrtf and IEEE
+// division, so whatever runs here must be correctly rounded too.  hipcc's sqrtf() expands to 17
+// VALU instructions and its division to 11 (input rescaling, class checks, v_div_scale /
+// v_div_fixup for the extreme exponents).  For 2^-96 <= x < 2^96 -- every discriminant, squared
+// length and length on the path -- two much shorter sequences give the SAME bits:
+//   sqrt:  y = v_rsq_f32(x); g = x*y; h = y/2; r = fma(-g, g, x); s = fma(r, h, g)      (5 VALU)
+//   1/s:   y = v_rcp_f32(s); e = fma(-s, y, 1); i = fma(e, y, y)                         (3 VALU)
+// (one Newton step whose residual the FMA forms exactly).  That is not argued but MEASURED:
+// tools/exhaust_sqrt.hip compares both with hipcc's correctly rounded forms on every one of the
+// 1,610,612,736 binary32 inputs of the range, on MI355X: 0 mismatches (profiles/r02/exhaust_sqrt.txt;
+// outside the range they do differ, so other inputs take the compiler's forms).
+LUMA_DEV bool lean_range(float x) { return x >= 0x1p-96f && x < 0x1p96f; }
+LUMA_DEV float sqrt_lean(float x)
+{
+    const float y = __builtin_amdgcn_rsqf(x);
+    const float g = x * y, h = 0.5f * y;
+    return fma_(fma_(-g, g, x), h, g);
+}
+LUMA_DEV float rcp_lean(float s)
+{
+    const float y = __builtin_amdgcn_rcpf(s);
+    return fma_(fma_(-s, y, 1.0f), y, y);
+}
 LUMA_DEV float sqrt_rn(float x)
 {
-    if (__builtin_expect(!(x >= 0x1p-96f && x < 0x1p96f), 0)) { return __builtin_sqrtf(x); }
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float s_dn = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
-    const float s_up = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
-    const float r_dn = fma_(-s_dn, s, x);
-    const float r_up = fma_(-s_up, s, x);
-    float r = (r_dn <= 0.0f) ? s_dn : s;
-    r = (r_up > 0.0f) ? s_up : r;
-    return r;
+    if (__builtin_expect(!lean_range(x), 0)) { return __builtin_sqrtf(x); }
+    return sqrt_lean(x);
 }
-LUMA_DEV f3 normalize3(f3 a) { float inv = 1.0f / sqrt_rn(dot3(a, a)); return scale3(a, inv); }
+// fx::normalize: v * (1 / sqrt(dot(v,v))).  dot in [2^-96, 2^96) puts the length in [2^-48, 2^48).
+LUMA_DEV f3 normalize3(f3 a)
+{
+    const float d = dot3(a, a);
+    float inv;
+    if (__builtin_expect(!lean_range(d), 0)) { inv = 1.0f / __builtin_sqrtf(d); }
+    else                                     { inv = rcp_lean(sqrt_lean(d)); }
+    return scale3(a, inv);
+}
 LUMA_DEV f3 fma3(f3 a, float s, f3 c) { return mk3(fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z)); }
 
 // exp() of the contract: Cody-Waite by ln2, degree-5 polynomial, 2^k through the exponent
