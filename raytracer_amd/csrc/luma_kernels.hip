@@ -182,7 +182,7 @@ LUMA_DEV f3 camera_ray(const RenderArgs& A, uint32_t x, uint32_t y)
 //   otherwise: `rec` = (centre.xyz, radius) and diff, c are formed per test (:244-248).
 // Returns the winning index (or -1) and t; hit point / normal are formed by the caller for
 // the winner only (the reference normalises every candidate, :264; same values).
-template <bool CAM_ORIGIN, bool UNROLL4>
+template <bool CAM_ORIGIN, bool UNROLL4, int NFIX = 0>
 LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin, f3 dir, float& t_out)
 {
     const float a = dot3(dir, dir);                              // :246 (hoisted: loop invariant)
@@ -234,6 +234,19 @@ LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin,
     // (Used for scenes big enough to run 16-wave workgroups; small scenes keep the plain
     // loop, whose 63 VGPRs allow 8 waves per SIMD.)
     uint32_t i = 0;
+    if (NFIX > 0) {
+        // the scene size is a compile-time constant (launch_render picks the instance): no loop
+        // counter and no address arithmetic
+#pragma unroll
+        for (int q = 0; q < NFIX; q++) {
+            float b, d;
+            test(rec[q], b, d);
+            consider(b, d, (uint32_t)q);
+            // (the reads stay where they are: hoisted ahead of the loop they cost 40 VGPRs and three waves per SIMD)
+            asm volatile("" ::: "memory");
+        }
+        i = n;
+    }
     if (UNROLL4) {
         for (; i + 4 <= n; i += 4) {
             const float4 s0 = rec[i], s1 = rec[i + 1], s2 = rec[i + 2], s3 = rec[i + 3];
@@ -425,7 +438,7 @@ enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 // (see `claim` below).
 // (GRID: the walk waits on dependent loads, so six waves per SIMD with ~40 B of spills beat four
 //  without: 2.93 -> 2.15 ms at 4096 spheres; five: 2.42, seven: 2.12 / 3.05 at 65536, eight: 2.60)
-template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT, bool GRID>
+template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT, bool GRID, int NS = 0>
 __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const RenderArgs A)
 {
     // [0,n): camera-origin records; [n,2n): general records; then mat0[n] (float4), mat1[n] (float2)
@@ -473,11 +486,11 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     // Renderer::trace_ray (:234-287): linear scan, or the same tests through the grid
     auto closest_cam = [&](f3 o, f3 d, float& t) {
         if (GRID) { return scan_grid<true>(A.grid, rec_cam, rec_gen, o, d, t, ntests); }
-        return scan_spheres<true, (SCENE == SCENE_GLOBAL)>(rec_cam, n, o, d, t);
+        return scan_spheres<true, (SCENE == SCENE_GLOBAL), NS>(rec_cam, n, o, d, t);
     };
     auto closest_gen = [&](f3 o, f3 d, float& t) {
         if (GRID) { return scan_grid<false>(A.grid, rec_cam, rec_gen, o, d, t, ntests); }
-        return scan_spheres<false, (SCENE == SCENE_GLOBAL)>(rec_gen, n, o, d, t);
+        return scan_spheres<false, (SCENE == SCENE_GLOBAL), NS>(rec_gen, n, o, d, t);
     };
 
     // DOF pre-pass, :416-432.  Noise free, so it is the same for every frame of the call; with
@@ -1131,6 +1144,18 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         };
 #undef LUMA_K
         k = table[split == 4 ? 2 : split == 2 ? 1 : 0][scene == SCENE_LDS_ALL][noise][from_hit];
+        // Scenes of up to 8 spheres (the reference's own has 5) with the reference's camera-origin bounce
+        // rays: instances with the sphere count as a compile-time constant, their scans fully unrolled
+        // (config #3: 1.93 -> 1.84 ms, profiles/r02/ab_unrolled_scan.txt)
+        if (scene == SCENE_LDS_ALL && !use_grid && !from_hit && n >= 1 && n <= 8) {
+#define LUMA_NS(P, N) { render_kernel<kTileW, 4, SCENE_LDS_ALL, false, false, P, false, N>, \
+                        render_kernel<kTileW, 4, SCENE_LDS_ALL, true, false, P, false, N> }
+#define LUMA_NS8(P) { LUMA_NS(P, 1), LUMA_NS(P, 2), LUMA_NS(P, 3), LUMA_NS(P, 4), LUMA_NS(P, 5), LUMA_NS(P, 6), LUMA_NS(P, 7), LUMA_NS(P, 8) }
+            static const kernel_t ns_table[3][8][2] = { LUMA_NS8(1), LUMA_NS8(2), LUMA_NS8(4) };
+#undef LUMA_NS8
+#undef LUMA_NS
+            k = ns_table[split == 4 ? 2 : split == 2 ? 1 : 0][n - 1][noise];
+        }
         if (use_grid) {                                          // records and materials stay in global memory
             lds = 0;
             k = grid_table[split == 4 ? 2 : split == 2 ? 1 : 0][noise][from_hit];
