@@ -44,10 +44,12 @@ enum {
     LUMA_FLAG_NO_SHOW_DEPTH   = 8u, /* skip the in-focus x1.2 (Renderer.cpp:448-454) regardless of camera.show_depth */
     LUMA_FLAG_PACK_RGBA8      = 16u, /* target bytes R,G,B,255 (0xFFBBGGRR) instead of ::RGB's 0x00RRGGBB (Renderer.cpp:44-55);
                                         same truncation and OR-combining, so combine with CLAMP_PACK for display use */
-    LUMA_FLAG_GRID            = 32u  /* closest-hit tests only against the spheres of the uniform-grid cells a ray crosses
-                                        instead of all of Renderer::spheres (Renderer.cpp:242); same tests, same winner,
-                                        same frame bit for bit, far fewer tests in large scenes.  luma_stats.sphere_tests
-                                        then counts the tests made.  Not the reference's scan: off by default */
+    LUMA_FLAG_GRID            = 32u  /* closest-hit tests only against the spheres a ray can reach instead of all of
+                                        Renderer::spheres (Renderer.cpp:242): rays from camera.pos (all primary and bounce
+                                        rays, :303) look their direction up in a cube-map grid around that point, rays from
+                                        hit points walk a uniform grid over the scene; same tests, same winner, same frame
+                                        bit for bit, far fewer tests in large scenes.  luma_stats.sphere_tests then counts
+                                        the tests made.  Not the reference's scan: off by default */
 };
 
 typedef struct luma_ctx luma_ctx;
@@ -299,6 +301,16 @@ typedef struct {
 } luma_grid_info;
 int luma_grid_describe(const luma_sphere* spheres, uint32_t n, luma_grid_info* info,
                        uint32_t* cell_start, uint32_t* items, uint32_t* large);
+
+/* The same for the direction grid LUMA_FLAG_GRID builds around camera.pos for the rays that start
+ * there (every primary and bounce ray of the reference, Renderer.cpp:303,:416): `res` bins per edge
+ * of each of six cube-map faces, bin (face*res + iv)*res + iu with face = 2*major axis + (negative),
+ * u and v the other two direction components (axis order) over |major|, mapped from [-1,1] to
+ * [0,res).  Call with the three arrays NULL for the sizes, then with cell_start[6*res*res + 1],
+ * items[n_items], large[n_large]. */
+int luma_view_grid_describe(const luma_sphere* spheres, uint32_t n, const float origin[3], uint32_t* res,
+                            uint32_t* n_items, uint32_t* n_large, uint32_t* cell_start, uint32_t* items,
+                            uint32_t* large);
 
 /* ---- diagnostics --------------------------------------------------------------- */
 const char* luma_hip_strerror(int code);

@@ -30,7 +30,7 @@ SYMBOLS = [
     "luma_hip_host_alloc", "luma_hip_host_free", "luma_grid_describe", "luma_hip_read_target",
     "luma_hip_render_device_noalloc",
     "luma_hip_group_render_device", "luma_hip_group_frame_device", "luma_hip_group_read_frame",
-    "luma_hip_reserve", "luma_hip_alloc_count", "luma_hip_group_reserve",
+    "luma_hip_reserve", "luma_hip_alloc_count", "luma_hip_group_reserve", "luma_view_grid_describe",
 ]
 
 
@@ -125,6 +125,7 @@ def lib():
         "luma_hip_host_alloc": (C.c_int, [ctxp, C.c_size_t]),
         "luma_hip_host_free": (None, [C.c_void_p]),
         "luma_grid_describe": (C.c_int, [C.POINTER(Sphere), C.c_uint32, C.POINTER(GridInfo), u32p, u32p, u32p]),
+        "luma_view_grid_describe": (C.c_int, [C.POINTER(Sphere), C.c_uint32, f32p, u32p, u32p, u32p, u32p, u32p, u32p]),
         "luma_hip_strerror": (C.c_char_p, [C.c_int]),
         "luma_hip_last_error": (C.c_char_p, []),
         "luma_hip_abi_version": (C.c_int, []),
@@ -215,6 +216,21 @@ def describe_grid(spheres):
     check(lib().luma_grid_describe(spheres if n else None, n, C.byref(info), _u32p(cell_start), _u32p(items), _u32p(large)),
           "luma_grid_describe")
     return info, cell_start, items[:info.n_items], large[:info.n_large]
+
+
+def describe_view_grid(spheres, origin):
+    """luma_view_grid_describe: (res, cell_start, items, large) as numpy arrays."""
+    n = len(spheres)
+    o = np.asarray(origin, dtype=np.float32)
+    res, n_items, n_large = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    check(lib().luma_view_grid_describe(spheres if n else None, n, _f32p(o), C.byref(res), C.byref(n_items), C.byref(n_large),
+                                        None, None, None), "luma_view_grid_describe")
+    cell_start = np.zeros(6 * res.value * res.value + 1, dtype=np.uint32)
+    items = np.zeros(max(n_items.value, 1), dtype=np.uint32)
+    large = np.zeros(max(n_large.value, 1), dtype=np.uint32)
+    check(lib().luma_view_grid_describe(spheres if n else None, n, _f32p(o), C.byref(res), C.byref(n_items), C.byref(n_large),
+                                        _u32p(cell_start), _u32p(items), _u32p(large)), "luma_view_grid_describe")
+    return res.value, cell_start, items[:n_items.value], large[:n_large.value]
 
 
 def device_count():

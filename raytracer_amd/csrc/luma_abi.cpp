@@ -120,6 +120,10 @@ struct luma_ctx {
     uint32_t* d_grid_cells = nullptr;
     uint32_t* d_grid_items = nullptr;
     uint32_t* d_grid_large = nullptr;
+    bool view_stale = true;                    // the direction grid around camera.pos (camera-origin rays)
+    uint32_t* d_view_start = nullptr;
+    uint32_t* d_view_items = nullptr;
+    uint32_t* d_view_large = nullptr;
 
     size_t band_pixels() const { return static_cast<size_t>(rows) * width; }
 };
@@ -202,37 +206,65 @@ int refresh_records(luma_ctx* ctx, hipStream_t stream)
     return LUMA_OK;
 }
 
-// LUMA_FLAG_GRID: build the grid from the scene on first use and after every luma_hip_set_scene.
+// LUMA_FLAG_GRID: build the uniform grid from the scene on first use and after every
+// luma_hip_set_scene, and the direction grid around camera.pos whenever the scene or that position
+// has changed since (luma_grid.h).
 int refresh_grid(luma_ctx* ctx)
 {
-    if (!ctx->grid_stale) { return LUMA_OK; }
-    luma::HostGrid g;
-    try {
-        luma::build_grid(ctx->host_spheres.data(), static_cast<uint32_t>(ctx->host_spheres.size()), g);
-    } catch (...) {
-        return fail(LUMA_E_NOMEM, "LUMA_FLAG_GRID", "host allocation failed while building the grid");
-    }
-    LUMA_HIP_TRY(hipDeviceSynchronize());                        // a launch may still walk the old grid
-    free_dev(ctx->d_grid_cells); free_dev(ctx->d_grid_items); free_dev(ctx->d_grid_large);
+    if (!ctx->grid_stale && !ctx->view_stale) { return LUMA_OK; }
     auto upload = [](uint32_t*& dst, const std::vector<uint32_t>& src) -> hipError_t {
         const size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(uint32_t);
         hipError_t e = hipMalloc(&dst, bytes);
         if (e == hipSuccess && !src.empty()) { e = hipMemcpy(dst, src.data(), src.size() * sizeof(uint32_t), hipMemcpyHostToDevice); }
         return e;
     };
-    LUMA_HIP_TRY(upload(ctx->d_grid_cells, g.cell_start));
-    LUMA_HIP_TRY(upload(ctx->d_grid_items, g.items));
-    LUMA_HIP_TRY(upload(ctx->d_grid_large, g.large));
-    ctx->device_allocs += 3;
     luma::GridArgs& a = ctx->grid;
-    for (int i = 0; i < 3; i++) { a.dims[i] = g.dims[i]; a.org[i] = g.org[i]; }
-    a.h = g.h;
-    a.inv_h = 1.0f / g.h;
-    a.cell_start = ctx->d_grid_cells;
-    a.items = ctx->d_grid_items;
-    a.large = ctx->d_grid_large;
-    a.n_large = static_cast<uint32_t>(g.large.size());
-    ctx->grid_stale = false;
+    const uint32_t n = static_cast<uint32_t>(ctx->host_spheres.size());
+    if (ctx->grid_stale) {
+        luma::HostGrid g;
+        try {
+            luma::build_grid(ctx->host_spheres.data(), n, g);
+        } catch (...) {
+            return fail(LUMA_E_NOMEM, "LUMA_FLAG_GRID", "host allocation failed while building the grid");
+        }
+        LUMA_HIP_TRY(hipDeviceSynchronize());                    // a launch may still walk the old grid
+        free_dev(ctx->d_grid_cells); free_dev(ctx->d_grid_items); free_dev(ctx->d_grid_large);
+        LUMA_HIP_TRY(upload(ctx->d_grid_cells, g.cell_start));
+        LUMA_HIP_TRY(upload(ctx->d_grid_items, g.items));
+        LUMA_HIP_TRY(upload(ctx->d_grid_large, g.large));
+        ctx->device_allocs += 3;
+        for (int i = 0; i < 3; i++) { a.dims[i] = g.dims[i]; a.org[i] = g.org[i]; }
+        a.h = g.h;
+        a.inv_h = 1.0f / g.h;
+        a.cell_start = ctx->d_grid_cells;
+        a.items = ctx->d_grid_items;
+        a.large = ctx->d_grid_large;
+        a.n_large = static_cast<uint32_t>(g.large.size());
+        ctx->grid_stale = false;
+        ctx->view_stale = true;
+    }
+    if (ctx->view_stale) {
+        luma::HostViewGrid v;
+        try {
+            luma::build_view_grid(ctx->host_spheres.data(), n, ctx->camera.pos, v);
+        } catch (...) {
+            return fail(LUMA_E_NOMEM, "LUMA_FLAG_GRID", "host allocation failed while building the direction grid");
+        }
+        LUMA_HIP_TRY(hipDeviceSynchronize());
+        free_dev(ctx->d_view_start); free_dev(ctx->d_view_items); free_dev(ctx->d_view_large);
+        a.view_res = 0;
+        LUMA_HIP_TRY(upload(ctx->d_view_start, v.cell_start));
+        LUMA_HIP_TRY(upload(ctx->d_view_items, v.items));
+        LUMA_HIP_TRY(upload(ctx->d_view_large, v.large));
+        ctx->device_allocs += 3;
+        a.view_res = v.res;
+        a.view_half_res = 0.5f * static_cast<float>(v.res);
+        a.view_start = ctx->d_view_start;
+        a.view_items = ctx->d_view_items;
+        a.view_large = ctx->d_view_large;
+        a.n_view_large = static_cast<uint32_t>(v.large.size());
+        ctx->view_stale = false;
+    }
     return LUMA_OK;
 }
 
@@ -470,6 +502,7 @@ void luma_hip_destroy(luma_ctx* ctx)
     free_dev(ctx->d_mat0); free_dev(ctx->d_mat1); free_dev(ctx->d_records);
     free_dev(ctx->d_acc); free_dev(ctx->d_target); free_dev(ctx->d_counters); free_dev(ctx->d_split);
     free_dev(ctx->d_grid_cells); free_dev(ctx->d_grid_items); free_dev(ctx->d_grid_large);
+    free_dev(ctx->d_view_start); free_dev(ctx->d_view_items); free_dev(ctx->d_view_large);
     if (ctx->h_counters) { (void)hipHostFree(ctx->h_counters); }
     if (ctx->ev_begin) { (void)hipEventDestroy(ctx->ev_begin); }
     if (ctx->ev_end) { (void)hipEventDestroy(ctx->ev_end); }
@@ -542,6 +575,7 @@ int luma_hip_set_camera(luma_ctx* ctx, const luma_camera* cam)
         // the scan records embed camera.pos; launches in flight (on any stream) read the old ones
         LUMA_HIP_TRY(hipDeviceSynchronize());
         ctx->records_stale = true;
+        ctx->view_stale = true;
     }
     ctx->camera = *cam;
     ctx->have_camera = true;
@@ -1312,6 +1346,23 @@ int luma_grid_describe(const luma_sphere* spheres, uint32_t n, luma_grid_info* i
     info->cell = g.h;
     info->n_items = static_cast<uint32_t>(g.items.size());
     info->n_large = static_cast<uint32_t>(g.large.size());
+    if (cell_start) { std::copy(g.cell_start.begin(), g.cell_start.end(), cell_start); }
+    if (items) { std::copy(g.items.begin(), g.items.end(), items); }
+    if (large) { std::copy(g.large.begin(), g.large.end(), large); }
+    return LUMA_OK;
+}
+
+int luma_view_grid_describe(const luma_sphere* spheres, uint32_t n, const float origin[3], uint32_t* res,
+                            uint32_t* n_items, uint32_t* n_large, uint32_t* cell_start, uint32_t* items, uint32_t* large)
+{
+    if (!origin || !res || !n_items || !n_large || (n > 0 && !spheres)) { return fail(LUMA_E_ARG, "luma_view_grid_describe", "null argument"); }
+    luma::HostViewGrid g;
+    try { luma::build_view_grid(spheres, n, origin, g); } catch (...) {
+        return fail(LUMA_E_NOMEM, "luma_view_grid_describe", "host allocation failed");
+    }
+    *res = g.res;
+    *n_items = static_cast<uint32_t>(g.items.size());
+    *n_large = static_cast<uint32_t>(g.large.size());
     if (cell_start) { std::copy(g.cell_start.begin(), g.cell_start.end(), cell_start); }
     if (items) { std::copy(g.items.begin(), g.items.end(), items); }
     if (large) { std::copy(g.large.begin(), g.large.end(), large); }

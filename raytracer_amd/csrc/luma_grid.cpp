@@ -128,4 +128,88 @@ void build_grid(const luma_sphere* spheres, uint32_t n, HostGrid& g)
     }
 }
 
+namespace {
+
+constexpr uint32_t kViewMaxBins = 2048;       // a sphere listed in more direction bins than this is "large"
+
+// Range of u = tan(angle) on one face, for directions whose projection on the (a, major) plane
+// passes through the disc that is the sphere's shadow there: centre angle phi, half-angle theta,
+// cut to the face's +-45 degrees.  False when the disc cannot be seen through this face.
+bool tangent_range(double qa, double qm, double r, double& lo, double& hi)
+{
+    const double quarter = 0.78539816339744830962, slack = 1e-6;
+    const double rho = std::hypot(qa, qm);
+    if (rho <= r) { lo = -1.0; hi = 1.0; return true; }     // the shadow covers the origin: every angle
+    const double phi = std::atan2(qa, qm), theta = std::asin(std::min(1.0, r / rho)) + slack;
+    bool any = false;
+    lo = 1.0; hi = -1.0;
+    for (int turn = -1; turn <= 1; turn++) {                  // the interval and its copies a full turn away
+        const double a0 = std::max(phi - theta + turn * 6.283185307179586, -quarter);
+        const double a1 = std::min(phi + theta + turn * 6.283185307179586, quarter);
+        if (a0 <= a1) { lo = std::min(lo, std::tan(a0)); hi = std::max(hi, std::tan(a1)); any = true; }
+    }
+    return any;
+}
+
+}  // namespace
+
+void build_view_grid(const luma_sphere* spheres, uint32_t n, const float origin[3], HostViewGrid& g)
+{
+    g = HostViewGrid{};
+    // bins about the angular size of a typical sphere: ~2 sqrt(n) per face edge, 16 .. 256
+    const uint32_t res = static_cast<uint32_t>(std::min(256.0, std::max(16.0, std::ceil(2.0 * std::sqrt(double(n) + 1.0)))));
+    g.res = res;
+    const size_t n_bins = size_t(6) * res * res;
+
+    struct Rect { uint32_t u0, u1, v0, v1; bool on; };
+    std::vector<Rect> rects(size_t(n) * 6, Rect{ 0, 0, 0, 0, false });
+    std::vector<uint8_t> small(n, 0);
+    auto bin_of = [&](double t) {                             // u or v in [-1, 1] -> bin index
+        return static_cast<long>(std::floor((t + 1.0) * 0.5 * res));
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const luma_sphere& s = spheres[i];
+        const double q[3] = { double(s.cx) - origin[0], double(s.cy) - origin[1], double(s.cz) - origin[2] };
+        const double dist = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+        // the float test can accept a hit a few ulp outside the sphere: pad well beyond that
+        const double r = std::fabs(double(s.radius)) * (1.0 + 1e-4) + 1e-5 * dist + 1e-30;
+        if (!std::isfinite(r) || !std::isfinite(dist) || dist <= r) { continue; }   // non-finite, or the origin is inside: large
+        uint64_t bins = 0;
+        for (int face = 0; face < 6; face++) {
+            const int m = face >> 1, a = (m + 1) % 3 < (m + 2) % 3 ? (m + 1) % 3 : (m + 2) % 3, b = 3 - m - a;   // u, v axes in axis order
+            const double sg = (face & 1) ? -1.0 : 1.0;
+            double ulo, uhi, vlo, vhi;
+            if (!tangent_range(q[a], sg * q[m], r, ulo, uhi) || !tangent_range(q[b], sg * q[m], r, vlo, vhi)) { continue; }
+            Rect& rc = rects[size_t(i) * 6 + face];
+            // one bin of margin each way: the kernel bins in float, with an approximate reciprocal
+            rc.u0 = static_cast<uint32_t>(std::max(0L, bin_of(ulo) - 1));
+            rc.u1 = static_cast<uint32_t>(std::min<long>(res - 1, bin_of(uhi) + 1));
+            rc.v0 = static_cast<uint32_t>(std::max(0L, bin_of(vlo) - 1));
+            rc.v1 = static_cast<uint32_t>(std::min<long>(res - 1, bin_of(vhi) + 1));
+            rc.on = true;
+            bins += uint64_t(rc.u1 - rc.u0 + 1) * (rc.v1 - rc.v0 + 1);
+        }
+        small[i] = bins <= kViewMaxBins;
+    }
+    std::vector<uint32_t> count(n_bins + 1, 0);
+    auto each_bin = [&](uint32_t i, auto&& fn) {
+        for (int face = 0; face < 6; face++) {
+            const Rect& rc = rects[size_t(i) * 6 + face];
+            if (!rc.on) { continue; }
+            for (uint32_t v = rc.v0; v <= rc.v1; v++) {
+                for (uint32_t u = rc.u0; u <= rc.u1; u++) { fn((size_t(face) * res + v) * res + u); }
+            }
+        }
+    };
+    for (uint32_t i = 0; i < n; i++) { if (small[i]) { each_bin(i, [&](size_t bin) { count[bin + 1]++; }); } }
+    for (size_t c = 0; c < n_bins; c++) { count[c + 1] += count[c]; }
+    g.cell_start = count;
+    g.items.assign(count[n_bins], 0);
+    std::vector<uint32_t> fill(count.begin(), count.end() - 1);
+    for (uint32_t i = 0; i < n; i++) {                        // ascending i => ascending inside every bin
+        if (!small[i]) { g.large.push_back(i); continue; }
+        each_bin(i, [&](size_t bin) { g.items[fill[bin]++] = i; });
+    }
+}
+
 }  // namespace luma

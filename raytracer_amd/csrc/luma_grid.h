@@ -24,4 +24,19 @@ struct HostGrid {
 // Never fails for finite n; spheres the grid cannot hold go to `large`.
 void build_grid(const luma_sphere* spheres, uint32_t n, HostGrid& out);
 
+// Direction grid around ONE origin: every primary and bounce ray of the reference starts at
+// camera.pos (Renderer.cpp:303, :416), so for those rays the spheres a ray can hit depend on its
+// direction alone.  The directions are binned on the six faces of a cube map, res x res bins per
+// face (bin = (face * res + iv) * res + iu; face = 2 * major axis + (negative ? 1 : 0); u, v = the
+// other two components in axis order, divided by |major|, in [-1, 1]); a bin lists, in ascending
+// order, every sphere that some direction of the bin can hit.  Rebuilt when the scene or camera.pos
+// changes.  `large`: spheres listed in too many bins (the ground) or that contain the origin.
+struct HostViewGrid {
+    uint32_t res = 1;
+    std::vector<uint32_t> cell_start;       // 6 * res * res + 1
+    std::vector<uint32_t> items;
+    std::vector<uint32_t> large;
+};
+void build_view_grid(const luma_sphere* spheres, uint32_t n, const float origin[3], HostViewGrid& out);
+
 }  // namespace luma

@@ -38,6 +38,13 @@ struct GridArgs {
     const uint32_t* items;         // sphere indices per cell, ascending
     const uint32_t* large;         // spheres tested against every ray
     uint32_t n_large;
+    // direction grid around camera.pos (luma_grid.h HostViewGrid), for the rays that start there
+    uint32_t view_res;             // bins per cube-map face edge; 0 = none (walk the uniform grid instead)
+    float    view_half_res;        // view_res / 2
+    const uint32_t* view_start;    // 6 * view_res^2 + 1
+    const uint32_t* view_items;    // sphere indices per bin, ascending
+    const uint32_t* view_large;
+    uint32_t n_view_large;
 };
 
 // Passed by value as the kernel argument (lands in SGPRs / the kernarg segment).

@@ -36,7 +36,7 @@ LUMA_DEV f3 neg3(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 LUMA_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 LUMA_DEV float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
 
-// Correctly rounded sqrt and reciprocal, short forms.  The oracle calls libm sqrtf and IEEE
+// Correctly rounded sqrt and reciprocal, short forms.  The arithmetic contract is libm sqrtf and IEEE
 // division, so whatever runs here must be correctly rounded too.  hipcc's sqrtf() expands to 17
 // VALU instructions and its division to 11 (input rescaling, class checks, v_div_scale /
 // v_div_fixup for the extreme exponents).  For 2^-96 <= x < 2^96 -- every discriminant, squared
@@ -379,6 +379,48 @@ LUMA_DEV int scan_grid(const GridArgs& G, const float4* __restrict__ rec_cam, co
     return best;
 }
 
+// Closest hit of a ray FROM camera.pos through the direction grid (FLAG_GRID; luma_grid.h
+// HostViewGrid): no walk at all, the ray's direction picks one bin of a cube map around camera.pos
+// and the bin lists every sphere such a ray can hit.  Same test, same (t, index) rule as scan_grid.
+LUMA_DEV int scan_view(const GridArgs& G, const float4* __restrict__ rec_cam, f3 dir, float& t_out, uint32_t& n_tests)
+{
+    const float a = dot3(dir, dir);                              // :246
+    float best_t = FLT_MAX;
+    int best = -1;
+    auto test = [&](uint32_t i) {
+        const float4 s = rec_cam[i];
+        const float b = dot3(mk3(s.x, s.y, s.z), dir);
+        const float d = fma_(b, b, -(a * s.w));
+        n_tests++;
+        if (d > 0.0f && b < 0.0f) {                              // :253
+            const float t = (-b - sqrt_rn(d)) / a;               // :255
+            if (t > 0.0f && (t < best_t || (t == best_t && (int)i < best))) { best_t = t; best = (int)i; }   // :258, :266
+        }
+    };
+    for (uint32_t j = 0; j < G.n_view_large; j++) { test(G.view_large[j]); }
+
+    // face = 2 * major axis + (negative), u and v = the other two components over |major|; the bins
+    // are padded by a whole bin on the host, so the approximate reciprocal is accurate enough
+    const float ax = __builtin_fabsf(dir.x), ay = __builtin_fabsf(dir.y), az = __builtin_fabsf(dir.z);
+    float major, u, v;
+    uint32_t face;
+    if (ax >= ay && ax >= az) { major = dir.x; u = dir.y; v = dir.z; face = 0u; }
+    else if (ay >= az)        { major = dir.y; u = dir.x; v = dir.z; face = 2u; }
+    else                      { major = dir.z; u = dir.x; v = dir.y; face = 4u; }
+    if (a > 0.0f && a < __builtin_inff()) {                      // (a zero or non-finite direction hits nothing small)
+        face += major < 0.0f ? 1u : 0u;
+        const float inv = __builtin_amdgcn_rcpf(__builtin_fabsf(major));
+        const int last = (int)G.view_res - 1;
+        const int iu = min(max((int)__builtin_floorf(fma_(u * inv, G.view_half_res, G.view_half_res)), 0), last);
+        const int iv = min(max((int)__builtin_floorf(fma_(v * inv, G.view_half_res, G.view_half_res)), 0), last);
+        const uint32_t bin = (face * G.view_res + (uint32_t)iv) * G.view_res + (uint32_t)iu;
+        const uint32_t k1 = G.view_start[bin + 1];
+        for (uint32_t k = G.view_start[bin]; k < k1; k++) { test(G.view_items[k]); }
+    }
+    t_out = best_t;
+    return best;
+}
+
 // ::RGB's shift-and-OR (Renderer.cpp:48-52), or the byte order R,G,B,255 for PACK_RGBA8.
 LUMA_DEV uint32_t pack_pixel(int r, int g, int b, uint32_t flags)
 {
@@ -485,7 +527,10 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
 
     // Renderer::trace_ray (:234-287): linear scan, or the same tests through the grid
     auto closest_cam = [&](f3 o, f3 d, float& t) {
-        if (GRID) { return scan_grid<true>(A.grid, rec_cam, rec_gen, o, d, t, ntests); }
+        if (GRID) {
+            if (A.grid.view_res) { return scan_view(A.grid, rec_cam, d, t, ntests); }   // every such ray starts at camera.pos
+            return scan_grid<true>(A.grid, rec_cam, rec_gen, o, d, t, ntests);
+        }
         return scan_spheres<true, (SCENE == SCENE_GLOBAL), NS>(rec_cam, n, o, d, t);
     };
     auto closest_gen = [&](f3 o, f3 d, float& t) {
