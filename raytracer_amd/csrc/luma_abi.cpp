@@ -240,6 +240,8 @@ int refresh_grid(luma_ctx* ctx)
         a.items = ctx->d_grid_items;
         a.large = ctx->d_grid_large;
         a.n_large = static_cast<uint32_t>(g.large.size());
+        // six workgroups per CU (the grid kernels' occupancy) x 26 KiB of 16-bit offsets fit the 160 KiB of LDS
+        a.lds_cells = (g.cell_start.size() <= 13312 && g.items.size() < 65536) ? static_cast<uint32_t>(g.cell_start.size()) : 0u;
         ctx->grid_stale = false;
         ctx->view_stale = true;
     }

@@ -38,6 +38,7 @@ struct GridArgs {
     const uint32_t* items;         // sphere indices per cell, ascending
     const uint32_t* large;         // spheres tested against every ray
     uint32_t n_large;
+    uint32_t lds_cells;            // entries of cell_start to stage in LDS as 16-bit words (0: read it from global memory)
     // direction grid around camera.pos (luma_grid.h HostViewGrid), for the rays that start there
     uint32_t view_res;             // bins per cube-map face edge; 0 = none (walk the uniform grid instead)
     float    view_half_res;        // view_res / 2

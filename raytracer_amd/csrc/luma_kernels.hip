@@ -287,8 +287,8 @@ LUMA_DEV Hit finish_hit(const float4* __restrict__ rec_gen, int idx, f3 origin, 
 // stops once the best hit lies before the exit of the current cell by a clear margin; the cell
 // lists are built from boxes padded by more than the arithmetic can displace a hit (luma_grid.cpp).
 template <bool CAM_ORIGIN>
-LUMA_DEV int scan_grid(const GridArgs& G, const float4* __restrict__ rec_cam, const float4* __restrict__ rec_gen,
-                       f3 origin, f3 dir, float& t_out, uint32_t& n_tests)
+LUMA_DEV int scan_grid(const GridArgs& G, const uint16_t* __restrict__ lds_cells, const float4* __restrict__ rec_cam,
+                       const float4* __restrict__ rec_gen, f3 origin, f3 dir, float& t_out, uint32_t& n_tests)
 {
     const float a = dot3(dir, dir);                              // :246
     float best_t = FLT_MAX;
@@ -354,9 +354,14 @@ LUMA_DEV int scan_grid(const GridArgs& G, const float4* __restrict__ rec_cam, co
         const float margin = 1e-3f * t_cell;
         const uint32_t most = G.dims[0] + G.dims[1] + G.dims[2] + 3u;    // a straight line crosses no more cells
         for (uint32_t hop = 0; hop < most; hop++) {
-            const size_t id = ((size_t)cz * G.dims[1] + (size_t)cy) * G.dims[0] + (size_t)cx;
-            const uint32_t k1 = G.cell_start[id + 1];
-            for (uint32_t k = G.cell_start[id]; k < k1; k++) { test(G.items[k]); }
+            // (at most 4M + 3 x 258^2 cells, luma_grid.cpp: the index fits 32 bits with room to spare)
+            const uint32_t id = ((uint32_t)cz * G.dims[1] + (uint32_t)cy) * G.dims[0] + (uint32_t)cx;
+            // the walk waits on this lookup at every hop: from the workgroup's LDS copy of the offsets
+            // (16 bit, staged by the kernel when the table fits) it costs an LDS round trip, not an L2 one
+            uint32_t k0, k1;
+            if (lds_cells) { k0 = lds_cells[id]; k1 = lds_cells[id + 1]; }
+            else           { k0 = G.cell_start[id]; k1 = G.cell_start[id + 1]; }
+            for (uint32_t k = k0; k < k1; k++) { test(G.items[k]); }
             const float t_exit = __builtin_fminf(__builtin_fminf(tx, ty), tz);
             if (best_t < t_exit - margin || t_exit > t1 + margin) { break; }
             // cross the nearest face (when two are due at once, one per hop)
@@ -506,6 +511,15 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
         __syncthreads();
     }
 
+    // FLAG_GRID: the uniform grid's cell offsets as 16-bit words in LDS, when launch_render found room
+    const uint16_t* grid_cells = nullptr;
+    if (GRID && A.grid.lds_cells) {
+        uint16_t* stage = reinterpret_cast<uint16_t*>(lds_rec);
+        for (uint32_t i = threadIdx.x; i < A.grid.lds_cells; i += blockDim.x) { stage[i] = (uint16_t)A.grid.cell_start[i]; }
+        __syncthreads();
+        grid_cells = stage;
+    }
+
     // lane -> pixel inside the wave tile; wave -> (frame block k, tile inside the workgroup)
     constexpr int TILE_H = 64 / TILE_W;
     constexpr int WPK = WAVES / SPLIT;                           // waves per frame block
@@ -529,12 +543,12 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     auto closest_cam = [&](f3 o, f3 d, float& t) {
         if (GRID) {
             if (A.grid.view_res) { return scan_view(A.grid, rec_cam, d, t, ntests); }   // every such ray starts at camera.pos
-            return scan_grid<true>(A.grid, rec_cam, rec_gen, o, d, t, ntests);
+            return scan_grid<true>(A.grid, grid_cells, rec_cam, rec_gen, o, d, t, ntests);
         }
         return scan_spheres<true, (SCENE == SCENE_GLOBAL), NS>(rec_cam, n, o, d, t);
     };
     auto closest_gen = [&](f3 o, f3 d, float& t) {
-        if (GRID) { return scan_grid<false>(A.grid, rec_cam, rec_gen, o, d, t, ntests); }
+        if (GRID) { return scan_grid<false>(A.grid, grid_cells, rec_cam, rec_gen, o, d, t, ntests); }
         return scan_spheres<false, (SCENE == SCENE_GLOBAL), NS>(rec_gen, n, o, d, t);
     };
 
@@ -1202,7 +1216,9 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
             k = ns_table[split == 4 ? 2 : split == 2 ? 1 : 0][n - 1][noise];
         }
         if (use_grid) {                                          // records and materials stay in global memory
-            lds = 0;
+            // the grid's cell offsets go to LDS as 16-bit words when six workgroups' copies fit a CU
+            // (the grid variants run six waves per SIMD) and the offsets fit 16 bits
+            lds = args.grid.lds_cells ? (((size_t)args.grid.lds_cells * sizeof(uint16_t) + 15u) & ~(size_t)15u) : 0;
             k = grid_table[split == 4 ? 2 : split == 2 ? 1 : 0][noise][from_hit];
         }
     }
