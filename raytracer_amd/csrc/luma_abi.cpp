@@ -122,7 +122,7 @@ struct luma_ctx {
     uint32_t* d_grid_large = nullptr;
     bool view_stale = true;                    // the direction grid around camera.pos (camera-origin rays)
     uint32_t* d_view_start = nullptr;
-    uint32_t* d_view_items = nullptr;
+    uint2*    d_view_items = nullptr;
     uint32_t* d_view_large = nullptr;
 
     size_t band_pixels() const { return static_cast<size_t>(rows) * width; }
@@ -255,8 +255,21 @@ int refresh_grid(luma_ctx* ctx)
         LUMA_HIP_TRY(hipDeviceSynchronize());
         free_dev(ctx->d_view_start); free_dev(ctx->d_view_items); free_dev(ctx->d_view_large);
         a.view_res = 0;
+        std::vector<uint32_t> pairs;                              // (index, nearest) interleaved: one 8-byte load per item
+        try {
+            pairs.resize(2 * v.items.size());
+            for (size_t k = 0; k < v.items.size(); k++) {
+                pairs[2 * k] = v.items[k];
+                std::memcpy(&pairs[2 * k + 1], &v.nearest[k], sizeof(float));
+            }
+        } catch (...) {
+            return fail(LUMA_E_NOMEM, "LUMA_FLAG_GRID", "host allocation failed while building the direction grid");
+        }
+        uint32_t* d_pairs = nullptr;
         LUMA_HIP_TRY(upload(ctx->d_view_start, v.cell_start));
-        LUMA_HIP_TRY(upload(ctx->d_view_items, v.items));
+        const hipError_t e_pairs = upload(d_pairs, pairs);
+        ctx->d_view_items = reinterpret_cast<uint2*>(d_pairs);    // owned by the context from here on, whatever e_pairs says
+        LUMA_HIP_TRY(e_pairs);
         LUMA_HIP_TRY(upload(ctx->d_view_large, v.large));
         ctx->device_allocs += 3;
         a.view_res = v.res;

@@ -164,6 +164,7 @@ void build_view_grid(const luma_sphere* spheres, uint32_t n, const float origin[
     struct Rect { uint32_t u0, u1, v0, v1; bool on; };
     std::vector<Rect> rects(size_t(n) * 6, Rect{ 0, 0, 0, 0, false });
     std::vector<uint8_t> small(n, 0);
+    std::vector<float> nearest(n, 0.f);
     auto bin_of = [&](double t) {                             // u or v in [-1, 1] -> bin index
         return static_cast<long>(std::floor((t + 1.0) * 0.5 * res));
     };
@@ -174,6 +175,7 @@ void build_view_grid(const luma_sphere* spheres, uint32_t n, const float origin[
         // the float test can accept a hit a few ulp outside the sphere: pad well beyond that
         const double r = std::fabs(double(s.radius)) * (1.0 + 1e-4) + 1e-5 * dist + 1e-30;
         if (!std::isfinite(r) || !std::isfinite(dist) || dist <= r) { continue; }   // non-finite, or the origin is inside: large
+        nearest[i] = static_cast<float>(std::max(0.0, (dist - r) * (1.0 - 1e-6)));   // (r is the padded radius: a lower bound)
         uint64_t bins = 0;
         for (int face = 0; face < 6; face++) {
             const int m = face >> 1, a = (m + 1) % 3 < (m + 2) % 3 ? (m + 1) % 3 : (m + 2) % 3, b = 3 - m - a;   // u, v axes in axis order
@@ -206,10 +208,18 @@ void build_view_grid(const luma_sphere* spheres, uint32_t n, const float origin[
     g.cell_start = count;
     g.items.assign(count[n_bins], 0);
     std::vector<uint32_t> fill(count.begin(), count.end() - 1);
-    for (uint32_t i = 0; i < n; i++) {                        // ascending i => ascending inside every bin
+    for (uint32_t i = 0; i < n; i++) {
         if (!small[i]) { g.large.push_back(i); continue; }
         each_bin(i, [&](size_t bin) { g.items[fill[bin]++] = i; });
     }
+    // nearest first inside every bin (ties by index, so the order is fully determined)
+    for (size_t c = 0; c < n_bins; c++) {
+        std::sort(g.items.begin() + count[c], g.items.begin() + count[c + 1], [&](uint32_t x, uint32_t y) {
+            return nearest[x] < nearest[y] || (nearest[x] == nearest[y] && x < y);
+        });
+    }
+    g.nearest.resize(g.items.size());
+    for (size_t k = 0; k < g.items.size(); k++) { g.nearest[k] = nearest[g.items[k]]; }
 }
 
 }  // namespace luma

@@ -43,7 +43,7 @@ struct GridArgs {
     uint32_t view_res;             // bins per cube-map face edge; 0 = none (walk the uniform grid instead)
     float    view_half_res;        // view_res / 2
     const uint32_t* view_start;    // 6 * view_res^2 + 1
-    const uint32_t* view_items;    // sphere indices per bin, ascending
+    const uint2*    view_items;    // per bin, nearest first: (sphere index, float bits of a lower bound of its distance from camera.pos)
     const uint32_t* view_large;
     uint32_t n_view_large;
 };
