@@ -89,6 +89,20 @@ for case in range(12):
         rng_seed=int(_rng.integers(0, 2**63)), posed=False, pos=[0.0, 0.0, 0.0], pitch=0.0, yaw=0.0, calls=1))
 
 
+# every sphere count that has an instance with the count as a compile-time constant (1..8), with and
+# without noise, one and several lanes per pixel (spp 1 forces one lane, larger spp on these small
+# frames takes four)
+for n in range(1, 9):
+    for flags in (0, 1):
+        kind = ["cluster", "around", "mirror", "wide"][n % 4]
+        CASES.append(dict(
+            id=f"fixed{n}-{kind}-f{flags}", kind=kind, n=n, scale=1.0, seed=int(_rng.integers(1, 2**31)),
+            W=int(_rng.integers(20, 70)), H=int(_rng.integers(10, 40)), spp=int(_rng.choice([1, 7])),
+            bounces=int(_rng.integers(1, 7)), paths=int(_rng.integers(0, 3)), samples=1, mode=1, flags=flags,
+            rng_seed=int(_rng.integers(0, 2**63)), posed=bool(n % 2), pos=[float(v) for v in _rng.uniform(-2, 2, size=3)],
+            pitch=float(_rng.uniform(-0.5, 0.5)), yaw=float(_rng.uniform(-1, 1)), calls=2))
+
+
 @pytest.mark.parametrize("c", CASES, ids=[c["id"] for c in CASES])
 def test_random_scene_matches_oracle(abi, oracle, c):
     rng = np.random.default_rng(c["seed"])
