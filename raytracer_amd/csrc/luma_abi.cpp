@@ -240,6 +240,8 @@ int refresh_grid(luma_ctx* ctx)
         a.items = ctx->d_grid_items;
         a.large = ctx->d_grid_large;
         a.n_large = static_cast<uint32_t>(g.large.size());
+        a.n_cells = static_cast<uint32_t>(g.cell_start.size());
+        a.n_items = static_cast<uint32_t>(g.items.size());
         // six workgroups per CU (the grid kernels' occupancy) x 26 KiB of 16-bit offsets fit the 160 KiB of LDS
         a.lds_cells = (g.cell_start.size() <= 13312 && g.items.size() < 65536) ? static_cast<uint32_t>(g.cell_start.size()) : 0u;
         ctx->grid_stale = false;
@@ -331,7 +333,7 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
         args.split_scratch = ctx->d_split;
     }
     ctx->last_split = args.split;
-    if (!grid && luma::sphere_parallel_scene(ctx->n_spheres)) {
+    if (luma::persistent_launch(ctx->n_spheres, grid)) {
         LUMA_HIP_TRY(hipMemsetAsync(args.tile_counter, 0, sizeof(uint32_t), stream));
     }
     // the events are only recorded for calls that report a luma_stats: each is a packet of its own

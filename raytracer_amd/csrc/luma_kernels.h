@@ -39,6 +39,7 @@ struct GridArgs {
     const uint32_t* large;         // spheres tested against every ray
     uint32_t n_large;
     uint32_t lds_cells;            // entries of cell_start to stage in LDS as 16-bit words (0: read it from global memory)
+    uint32_t n_cells, n_items;     // entries of cell_start / items
     // direction grid around camera.pos (luma_grid.h HostViewGrid), for the rays that start there
     uint32_t view_res;             // bins per cube-map face edge; 0 = none (walk the uniform grid instead)
     float    view_half_res;        // view_res / 2
@@ -95,6 +96,7 @@ hipError_t static_scratch_address(void** ptr);
 
 size_t     scene_lds_bytes(uint32_t n_spheres);
 bool       sphere_parallel_scene(uint32_t n_spheres);
+bool       persistent_launch(uint32_t n_spheres, bool grid);
 uint32_t   choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid);
 hipError_t launch_prepare_records(const float* cx, const float* cy, const float* cz, const float* rad,
                                   uint32_t n, const float pos[3], float4* records, hipStream_t stream);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <mutex>
@@ -269,6 +270,15 @@ LUMA_DEV int scan_spheres(const float4* __restrict__ rec, uint32_t n, f3 origin,
     return best;
 }
 
+
+// Debug builds (-DLUMA_DBG_WALK=1|2|3) turn the sphere-test counter of scan_grid<false> / wave_grid_walk into
+// 1: hops summed over lanes, 2: hop-loop trips of the wave, 3: test-body trips of the wave (tools/grid_walk_stats.py)
+#ifndef LUMA_DBG_WALK
+#define LUMA_DBG_WALK 0
+#endif
+#define LUMA_WAVE_ONCE(CNT) do { const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true); \
+                               if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m_)) { (CNT)++; } } while (0)
+
 struct Hit { f3 pos, normal; };
 
 LUMA_DEV Hit finish_hit(const float4* __restrict__ rec_gen, int idx, f3 origin, f3 dir, float t)
@@ -306,7 +316,8 @@ LUMA_DEV int scan_grid(const GridArgs& G, const uint16_t* __restrict__ lds_cells
             c = fma_(-s.w, s.w, dot3(diff, diff));               // :248
         }
         const float d = fma_(b, b, -(a * c));
-        n_tests++;
+        if (LUMA_DBG_WALK == 0 || CAM_ORIGIN) { n_tests++; }
+        if (LUMA_DBG_WALK == 3 && !CAM_ORIGIN) { LUMA_WAVE_ONCE(n_tests); }
         if (d > 0.0f && b < 0.0f) {                              // :253
             const float t = (-b - sqrt_rn(d)) / a;               // :255
             if (t > 0.0f && (t < best_t || (t == best_t && (int)i < best))) { best_t = t; best = (int)i; }   // :258, :266
@@ -354,6 +365,8 @@ LUMA_DEV int scan_grid(const GridArgs& G, const uint16_t* __restrict__ lds_cells
         const float margin = 1e-3f * t_cell;
         const uint32_t most = G.dims[0] + G.dims[1] + G.dims[2] + 3u;    // a straight line crosses no more cells
         for (uint32_t hop = 0; hop < most; hop++) {
+            if (LUMA_DBG_WALK == 1 && !CAM_ORIGIN) { n_tests++; }
+            if (LUMA_DBG_WALK == 2 && !CAM_ORIGIN) { LUMA_WAVE_ONCE(n_tests); }
             // (at most 4M + 3 x 258^2 cells, luma_grid.cpp: the index fits 32 bits with room to spare)
             const uint32_t id = ((uint32_t)cz * G.dims[1] + (uint32_t)cy) * G.dims[0] + (uint32_t)cx;
             // the walk waits on this lookup at every hop: from the workgroup's LDS copy of the offsets
@@ -396,7 +409,7 @@ LUMA_DEV int scan_view(const GridArgs& G, const float4* __restrict__ rec_cam, f3
         const float4 s = rec_cam[i];
         const float b = dot3(mk3(s.x, s.y, s.z), dir);
         const float d = fma_(b, b, -(a * s.w));
-        n_tests++;
+        if (LUMA_DBG_WALK == 0) { n_tests++; }
         if (d > 0.0f && b < 0.0f) {                              // :253
             const float t = (-b - sqrt_rn(d)) / a;               // :255
             if (t > 0.0f && (t < best_t || (t == best_t && (int)i < best))) { best_t = t; best = (int)i; }   // :258, :266
@@ -858,14 +871,232 @@ LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t
     }
 }
 
-template <int TILE_W, int WAVES, bool NOISE, bool FROM_HIT>
+// ---------------------------------------------------------------------------------
+// FLAG_GRID in the wave-uniform kernel: the walk of the uniform grid shared by the wave.
+//
+// In render_kernel the rays from hit points walk the grid one ray per lane INSIDE the divergent hit
+// side: the lanes without such a ray idle through the whole walk and the lanes with one wait for the
+// longest walk of the wave (12.5 % active lanes per instruction).  Here every lane of the wave takes
+// part: the W rays that need a walk are numbered, their origin / direction / parameter range go
+// through LDS, and each ray is given L = 8, 4, 2 or 1 ADJACENT lanes (the largest power of two with
+// W * L <= 64), lane s of the L walking the s-th L-th of the ray's parameter range inside the grid
+// (a 3D-DDA entered at the start of the segment).  A hit whose point lies in a segment is found by
+// that segment's lane, because the sphere is listed in the cell that holds the point; hits a lane
+// finds beyond its segment are real hits all the same.  The L results are folded by (t, index)
+// lexicographic minimum -- the reference's closest-hit rule (Renderer.cpp:266), which does not depend
+// on the order of the tests -- and handed back to the ray's lane.  Later segments are walked
+// speculatively (an earlier one may already hold the hit); the price is paid in lanes that were idle.
+// ---------------------------------------------------------------------------------
+constexpr uint32_t kCoopSlotsPerWave = 64u + 16u;              // float4 slots: 32 rays x 2, then 32 results x 8 B
+LUMA_DEV uint32_t lane_of_wave() { return threadIdx.x & 63u; }
+
+struct CoopLds {
+    float4* ray;        // per wave: 32 x 2 float4: (origin.xyz, t0), (dir.xyz, t1)
+    uint2*  res;        // per wave: 32 x (t bits, index)
+};
+
+template <bool RES>
+LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds_cells, const uint16_t* __restrict__ lds_items,
+                             const float4* __restrict__ rec_gen, const CoopLds X, uint32_t lane, bool want, f3 origin, f3 dir,
+                             int& idx_out, float& t_out, uint32_t& n_tests)
+{
+    float best_t = FLT_MAX;
+    uint32_t best = 0xFFFFFFFFu;
+    // the reference's test (:244-258) for the ray (o, d) with a = dot(d, d); winner by (t, index)
+    auto test = [&](uint32_t i, f3 o, f3 d, float a) {
+        const float4 s = rec_gen[i];
+        const f3 diff = sub3(o, mk3(s.x, s.y, s.z));             // :244
+        const float b = dot3(diff, d);
+        const float c = fma_(-s.w, s.w, dot3(diff, diff));       // :248
+        const float dd = fma_(b, b, -(a * c));
+        if (LUMA_DBG_WALK == 0) { n_tests++; }
+        if (LUMA_DBG_WALK == 3) { LUMA_WAVE_ONCE(n_tests); }
+        if (dd > 0.0f && b < 0.0f) {                             // :253
+            const float t = (-b - sqrt_rn(dd)) / a;              // :255
+            if (t > 0.0f && (t < best_t || (t == best_t && i < best))) { best_t = t; best = i; }   // :258, :266
+        }
+    };
+
+    // ---- own ray: the always-tested spheres, and the part of the ray inside the grid's box ----
+    const float a_own = dot3(dir, dir);
+    float t0 = 0.0f, t1 = FLT_MAX;
+    bool inside = want;
+    if (want) {
+        for (uint32_t j = 0; j < G.n_large; j++) { test(G.large[j], origin, dir, a_own); }
+        auto clip = [&](float o, float d, float org, uint32_t dim) {
+            const float lo = org, hi = org + (float)dim * G.h;
+            if (d != 0.0f) {
+                const float inv = 1.0f / d;
+                const float ta = (lo - o) * inv, tb = (hi - o) * inv;
+                t0 = __builtin_fmaxf(t0, __builtin_fminf(ta, tb));
+                t1 = __builtin_fminf(t1, __builtin_fmaxf(ta, tb));
+            } else {
+                inside = inside && (o >= lo && o <= hi);
+            }
+        };
+        clip(origin.x, dir.x, G.org[0], G.dims[0]);
+        clip(origin.y, dir.y, G.org[1], G.dims[1]);
+        clip(origin.z, dir.z, G.org[2], G.dims[2]);
+    }
+    const bool walk = inside && t0 <= t1 && a_own > 0.0f;
+    const float own_t = best_t;
+    const uint32_t own_i = best;
+
+    // ---- hand the rays out: rank r of the W walking rays goes to lanes [r * L, (r + 1) * L) ----
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(walk);
+    const uint32_t W = (uint32_t)__builtin_popcountll(mask);
+    idx_out = (int)own_i;
+    t_out = own_t;
+    if (W == 0u) { return; }                                     // wave uniform
+    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+    const uint32_t L = W <= 8u ? 8u : W <= 16u ? 4u : W <= 32u ? 2u : 1u;   // wave uniform
+    uint32_t q = lane, seg = 0u;
+    bool have = walk;
+    f3 o = origin, d = dir;
+    float r_t0 = t0, r_t1 = t1;
+    if (L > 1u) {                                                // more than 32 rays: every lane walks its own
+        if (walk) {
+            X.ray[2u * rank] = make_float4(origin.x, origin.y, origin.z, t0);
+            X.ray[2u * rank + 1u] = make_float4(dir.x, dir.y, dir.z, t1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        q = lane / L;
+        seg = lane % L;
+        have = q < W;
+        if (have) {
+            const float4 r0 = X.ray[2u * q], r1 = X.ray[2u * q + 1u];
+            o = mk3(r0.x, r0.y, r0.z);
+            d = mk3(r1.x, r1.y, r1.z);
+            r_t0 = r0.w;
+            r_t1 = r1.w;
+        }
+    }
+
+    best_t = FLT_MAX;
+    best = 0xFFFFFFFFu;
+    // this lane's share of [t0, t1]; a range too long to cut (t1 overflowed) goes to the first lane whole
+    const float span = (r_t1 - r_t0) / (float)L;
+    const bool cut = span < FLT_MAX;
+    const float ts = (cut && seg > 0u) ? fma_(span, (float)seg, r_t0) : r_t0;
+    const float te = (cut && seg + 1u < L) ? fma_(span, (float)(seg + 1u), r_t0) : r_t1;
+    if (have && (cut || seg == 0u)) {
+        const float a = dot3(d, d);
+        float t_cell = FLT_MAX;                                  // time to cross one cell along the fastest axis
+        auto enter = [&](float oc, float dc, float org, uint32_t dim, int& cell, float& t_next, float& inv) {
+            const float p = fma_(dc, ts, oc);
+            cell = min(max((int)__builtin_floorf((p - org) * G.inv_h), 0), (int)dim - 1);
+            if (dc != 0.0f) {
+                inv = 1.0f / dc;
+                t_next = (org + (float)(cell + (dc > 0.0f ? 1 : 0)) * G.h - oc) * inv;
+                t_cell = __builtin_fminf(t_cell, G.h * __builtin_fabsf(inv));
+            } else {
+                inv = 0.0f;
+                t_next = FLT_MAX;
+            }
+        };
+        int cx, cy, cz;
+        float tx, ty, tz, ix, iy, iz;
+        enter(o.x, d.x, G.org[0], G.dims[0], cx, tx, ix);
+        enter(o.y, d.y, G.org[1], G.dims[1], cy, ty, iy);
+        enter(o.z, d.z, G.org[2], G.dims[2], cz, tz, iz);
+        const float margin = 1e-3f * t_cell;
+        const uint32_t most = G.dims[0] + G.dims[1] + G.dims[2] + 3u;    // a straight line crosses no more cells
+        for (uint32_t hop = 0; hop < most; hop++) {
+            if (LUMA_DBG_WALK == 1) { n_tests++; }
+            if (LUMA_DBG_WALK == 2) { LUMA_WAVE_ONCE(n_tests); }
+            const uint32_t id = ((uint32_t)cz * G.dims[1] + (uint32_t)cy) * G.dims[0] + (uint32_t)cx;
+            uint32_t k0, k1;
+            if (RES || lds_cells) { k0 = lds_cells[id]; k1 = lds_cells[id + 1]; }
+            else                  { k0 = G.cell_start[id]; k1 = G.cell_start[id + 1]; }
+            for (uint32_t k = k0; k < k1; k++) { test(RES ? (uint32_t)lds_items[k] : G.items[k], o, d, a); }
+            const float t_exit = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+            if (best_t < t_exit - margin || t_exit > te + margin) { break; }
+            if (tx <= ty && tx <= tz) {
+                cx += d.x > 0.0f ? 1 : -1;
+                if (cx < 0 || cx >= (int)G.dims[0]) { break; }
+                tx = (G.org[0] + (float)(cx + (d.x > 0.0f ? 1 : 0)) * G.h - o.x) * ix;
+            } else if (ty <= tz) {
+                cy += d.y > 0.0f ? 1 : -1;
+                if (cy < 0 || cy >= (int)G.dims[1]) { break; }
+                ty = (G.org[1] + (float)(cy + (d.y > 0.0f ? 1 : 0)) * G.h - o.y) * iy;
+            } else {
+                cz += d.z > 0.0f ? 1 : -1;
+                if (cz < 0 || cz >= (int)G.dims[2]) { break; }
+                tz = (G.org[2] + (float)(cz + (d.z > 0.0f ? 1 : 0)) * G.h - o.z) * iz;
+            }
+        }
+    }
+
+    // ---- fold the L lanes of each ray: smallest t, lowest index among equal t ----
+    uint32_t bt = __builtin_bit_cast(uint32_t, best_t), bi = best;   // t > 0: its bit pattern orders like its value
+    for (uint32_t off = 1u; off < L; off <<= 1) {
+        const uint32_t ot = (uint32_t)__shfl_xor((int)bt, (int)off, 64), oi = (uint32_t)__shfl_xor((int)bi, (int)off, 64);
+        if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; }
+    }
+    uint2 r = make_uint2(bt, bi);
+    if (L > 1u) {
+        if (have && seg == 0u) { X.res[q] = r; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (walk) { r = X.res[rank]; }
+    }
+    if (walk) {
+        const float rt = __builtin_bit_cast(float, r.x);
+        float ft = own_t;
+        uint32_t fi = own_i;
+        if (r.y != 0xFFFFFFFFu && (rt < ft || (rt == ft && r.y < fi))) { ft = rt; fi = r.y; }
+        idx_out = (int)fi;
+        t_out = ft;
+    }
+}
+
+template <int TILE_W, int WAVES, bool NOISE, bool FROM_HIT, bool GRID = false, bool RES = false>
 __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs A)
 {
     // [0,n_pad): camera-origin records; [n_pad,2 n_pad): general records; padding = NaN
+    // GRID: the camera-origin records stay in global memory; LDS holds the uniform grid's cell offsets
+    // as 16-bit words (when launch_render found room) and each wave's exchange area for wave_grid_walk.
+    // GRID && RES (the whole walk is LDS resident: launch_render found room for all of it): the general
+    // records [0,n), then the cell offsets and the cells' sphere lists as 16-bit words, then the
+    // exchange areas -- a hop of the walk and a sphere test wait on LDS, not on L2, round trips.
     extern __shared__ float4 lds_rec[];
     const uint32_t n = A.n_spheres;
     const uint32_t n_pad = (n + 63u) & ~63u;
-    {
+    const float4* rec_cam = lds_rec;
+    const float4* rec_gen = lds_rec + n_pad;
+    const uint16_t* grid_cells = nullptr;
+    const uint16_t* grid_items = nullptr;
+    CoopLds xch = { nullptr, nullptr };
+    if (GRID) {
+        rec_cam = A.records;
+        rec_gen = A.records + n;
+        float4* next = lds_rec;
+        if (RES) {
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { next[i] = A.records[n + i]; }
+            rec_gen = next;
+            next += n;
+        }
+        const uint32_t n_cells = RES ? A.grid.n_cells : A.grid.lds_cells;
+        if (n_cells) {
+            uint16_t* stage = reinterpret_cast<uint16_t*>(next);
+            for (uint32_t i = threadIdx.x; i < n_cells; i += blockDim.x) { stage[i] = (uint16_t)A.grid.cell_start[i]; }
+            grid_cells = stage;
+            next += (n_cells + 7u) / 8u;                         // float4 slots of 16-bit words
+        }
+        if (RES) {
+            uint16_t* stage = reinterpret_cast<uint16_t*>(next);
+            for (uint32_t i = threadIdx.x; i < A.grid.n_items; i += blockDim.x) { stage[i] = (uint16_t)A.grid.items[i]; }
+            grid_items = stage;
+            next += (A.grid.n_items + 7u) / 8u;
+        }
+        float4* mine = next + (threadIdx.x >> 6) * kCoopSlotsPerWave;
+        xch.ray = mine;
+        xch.res = reinterpret_cast<uint2*>(mine + 64);
+        __syncthreads();
+    } else {
         const float qnan = __builtin_nanf("");
         const float4 never = make_float4(qnan, qnan, qnan, qnan);
         for (uint32_t i = threadIdx.x; i < n_pad; i += blockDim.x) {
@@ -876,8 +1107,21 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         }
         __syncthreads();
     }
-    const float4* rec_cam = lds_rec;
-    const float4* rec_gen = lds_rec + n_pad;
+    uint32_t ntests = 0;
+    // Renderer::trace_ray (:234-287) for the wave: a ray from camera.pos / from anywhere, for the lanes that `want` one
+    auto scan_cam = [&](bool want, f3 o, f3 d, int& idx, float& t) {
+        if (GRID) {
+            idx = -1;
+            t = FLT_MAX;
+            if (want) { idx = scan_view(A.grid, rec_cam, d, t, ntests); }    // direction grid: no walk, one lane per ray
+        } else {
+            wave_scan<true>(rec_cam, n_pad, lane_of_wave(), want, o, d, idx, t);
+        }
+    };
+    auto scan_gen = [&](bool want, f3 o, f3 d, int& idx, float& t) {
+        if (GRID) { wave_grid_walk<RES>(A.grid, grid_cells, grid_items, rec_gen, xch, lane_of_wave(), want, o, d, idx, t, ntests); }
+        else      { wave_scan<false>(rec_gen, n_pad, lane_of_wave(), want, o, d, idx, t); }
+    };
 
     // Persistent waves: the grid is one resident set of workgroups (the 128-KiB record image
     // allows one 16-wave workgroup per CU), and each wave pulls 16x4-pixel tiles from a global
@@ -911,7 +1155,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     // DOF pre-pass, :416-432
     int h0;
     float t0;
-    wave_scan<true>(rec_cam, n_pad, lane, live, campos, dir0, h0, t0);
+    scan_cam(live, campos, dir0, h0, t0);
     nrays += live ? 1u : 0u;
     const float depth = (h0 >= 0) ? t0 : FLT_MAX;                // :419-423
     const float dd = depth - A.focus_depth;                      // :425
@@ -946,11 +1190,11 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         float t;
         if (FROM_HIT) {
             int i2; float t2;
-            wave_scan<true>(rec_cam, n_pad, lane, active && bounce == 0, origin, dn, idx, t);
-            wave_scan<false>(rec_gen, n_pad, lane, active && bounce > 0, origin, dn, i2, t2);
+            scan_cam(active && bounce == 0, origin, dn, idx, t);
+            scan_gen(active && bounce > 0, origin, dn, i2, t2);
             if (bounce > 0) { idx = i2; t = t2; }
         } else {
-            wave_scan<true>(rec_cam, n_pad, lane, active, origin, dn, idx, t);   // :304
+            scan_cam(active, origin, dn, idx, t);                // :304
         }
         nrays += active ? 1u : 0u;
 
@@ -986,7 +1230,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
                 nd = add3(hit.normal, d);                        // :202
             }
             int ci; float tc;
-            wave_scan<false>(rec_gen, n_pad, lane, want_indirect, hit.pos, nd, ci, tc);   // :204
+            scan_gen(want_indirect, hit.pos, nd, ci, tc);        // :204
             if (want_indirect) {
                 nrays++;
                 if (ci >= 0) {                                   // :206-209
@@ -1048,6 +1292,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
   }  // next tile
 
     wave_add_u64(A.counters, nrays);
+    if (GRID) { wave_add_u64(A.counters + 1, ntests); wave_add_u64(A.counters + 2, nrays); }   // tests, and rays of grid launches
 }
 
 // Per-sphere records for the scan, rebuilt when the scene or the camera position changes:
@@ -1102,9 +1347,22 @@ bool sphere_parallel_scene(uint32_t n_spheres)
         && (size_t)((n_spheres + 63u) & ~63u) * 2u * sizeof(float4) <= kMaxSceneLdsBytes;
 }
 
+// FLAG_GRID launches whose rays from hit points walk the grid as a wave (wave_grid_walk)
+bool grid_wave_walk(uint32_t n_spheres)
+{
+    static const bool on = [] { const char* e = getenv("LUMA_GRID_COOP"); return e && *e == '1'; }();
+    return on && n_spheres > 0;
+}
+
+// Launches that hand out wave tiles through RenderArgs::tile_counter (it must be zero at the start)
+bool persistent_launch(uint32_t n_spheres, bool grid)
+{
+    return grid ? grid_wave_walk(n_spheres) : sphere_parallel_scene(n_spheres);
+}
+
 uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid)
 {
-    if (!grid && sphere_parallel_scene(n_spheres)) { return 1; }
+    if (persistent_launch(n_spheres, grid)) { return 1; }
     // measured on MI355X, bands of the 1080p x 64 spp frame (kernel ms for 1 / 2 / 4 lanes per pixel):
     // 2.07M px 2.09 / 2.13 / 2.32, 1.04M px 1.17 / 1.11 / 1.17, 518k px 0.66 / 0.61 / 0.60,
     // 259k px 0.50 / 0.36 / 0.33
@@ -1177,8 +1435,23 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     size_t lds;
     int waves, split = 1;
     const bool use_grid = (args.flags & FLAG_GRID) != 0 && n > 0;
-    const bool sphere_parallel = !use_grid && sphere_parallel_scene(n);
-    if (sphere_parallel) {
+    const bool sphere_parallel = persistent_launch(n, use_grid);
+    if (sphere_parallel && use_grid) {
+        // wave_grid_walk: the general records, the cell offsets and the cells' sphere lists (16-bit words) all in
+        // LDS when they fit beside the waves' exchange areas -- one 16-wave workgroup per CU; else 8-wave workgroups
+        // with the cell offsets only (<= 26 KiB), when refresh_grid found those small enough
+        const GridArgs& g = args.grid;
+        const size_t res_slots = (size_t)n + (g.n_cells + 7u) / 8u + (g.n_items + 7u) / 8u + 16u * kCoopSlotsPerWave;
+        const bool resident = n < 65536u && g.n_items < 65536u && res_slots * sizeof(float4) <= 156u * 1024u;
+        waves = resident ? 16 : 8;
+        lds = resident ? res_slots * sizeof(float4)
+                       : ((((size_t)g.lds_cells + 7u) / 8u) + (size_t)waves * kCoopSlotsPerWave) * sizeof(float4);
+#define LUMA_COOP(W, R) { { render_kernel_sp<kTileW, W, false, false, true, R>, render_kernel_sp<kTileW, W, false, true, true, R> }, \
+                          { render_kernel_sp<kTileW, W, true, false, true, R>,  render_kernel_sp<kTileW, W, true, true, true, R> } }
+        static const kernel_t coop_table[2][2][2] = { LUMA_COOP(8, false), LUMA_COOP(16, true) };
+#undef LUMA_COOP
+        k = coop_table[resident][noise][from_hit];
+    } else if (sphere_parallel) {
         // The kernel needs ~90 VGPRs, so a SIMD holds 5 waves: five 4-wave workgroups per CU
         // (20 waves) fit while each needs <= 32 KiB of the 160 KiB LDS; beyond that one 16-wave
         // workgroup per CU (a second would need 8 waves per SIMD).  640 -> 641 spheres cost 19 %
