@@ -400,13 +400,21 @@ LUMA_DEV int scan_grid(const GridArgs& G, const uint16_t* __restrict__ lds_cells
 // Closest hit of a ray FROM camera.pos through the direction grid (FLAG_GRID; luma_grid.h
 // HostViewGrid): no walk at all, the ray's direction picks one bin of a cube map around camera.pos
 // and the bin lists every sphere such a ray can hit.  Same test, same (t, index) rule as scan_grid.
-LUMA_DEV int scan_view(const GridArgs& G, const float4* __restrict__ rec_cam, f3 dir, float& t_out, uint32_t& n_tests)
+// FROM_GEN: `rec` holds the general records (centre, radius) and the test derives the camera-origin record
+// from them with prepare_records_kernel's own arithmetic (the same bits), for kernels that keep only the
+// general records in LDS.
+template <bool FROM_GEN = false>
+LUMA_DEV int scan_view(const GridArgs& G, const float4* __restrict__ rec, f3 campos, f3 dir, float& t_out, uint32_t& n_tests)
 {
     const float a = dot3(dir, dir);                              // :246
     float best_t = FLT_MAX;
     int best = -1;
     auto test = [&](uint32_t i) {
-        const float4 s = rec_cam[i];
+        float4 s = rec[i];
+        if (FROM_GEN) {
+            const f3 diff = sub3(campos, mk3(s.x, s.y, s.z));
+            s = make_float4(diff.x, diff.y, diff.z, fma_(-s.w, s.w, dot3(diff, diff)));
+        }
         const float b = dot3(mk3(s.x, s.y, s.z), dir);
         const float d = fma_(b, b, -(a * s.w));
         if (LUMA_DBG_WALK == 0) { n_tests++; }
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     // Renderer::trace_ray (:234-287): linear scan, or the same tests through the grid
     auto closest_cam = [&](f3 o, f3 d, float& t) {
         if (GRID) {
-            if (A.grid.view_res) { return scan_view(A.grid, rec_cam, d, t, ntests); }   // every such ray starts at camera.pos
+            if (A.grid.view_res) { return scan_view(A.grid, rec_cam, campos, d, t, ntests); }   // every such ray starts at camera.pos
             return scan_grid<true>(A.grid, grid_cells, rec_cam, rec_gen, o, d, t, ntests);
         }
         return scan_spheres<true, (SCENE == SCENE_GLOBAL), NS>(rec_cam, n, o, d, t);
@@ -875,35 +883,53 @@ LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t
 // FLAG_GRID in the wave-uniform kernel: the walk of the uniform grid shared by the wave.
 //
 // In render_kernel the rays from hit points walk the grid one ray per lane INSIDE the divergent hit
-// side: the lanes without such a ray idle through the whole walk and the lanes with one wait for the
-// longest walk of the wave (12.5 % active lanes per instruction).  Here every lane of the wave takes
-// part: the W rays that need a walk are numbered, their origin / direction / parameter range go
-// through LDS, and each ray is given L = 8, 4, 2 or 1 ADJACENT lanes (the largest power of two with
-// W * L <= 64), lane s of the L walking the s-th L-th of the ray's parameter range inside the grid
-// (a 3D-DDA entered at the start of the segment).  A hit whose point lies in a segment is found by
-// that segment's lane, because the sphere is listed in the cell that holds the point; hits a lane
-// finds beyond its segment are real hits all the same.  The L results are folded by (t, index)
-// lexicographic minimum -- the reference's closest-hit rule (Renderer.cpp:266), which does not depend
-// on the order of the tests -- and handed back to the ray's lane.  Later segments are walked
-// speculatively (an earlier one may already hold the hit); the price is paid in lanes that were idle.
+// side: the lanes without such a ray idle through the whole walk, the lanes with one wait for the
+// longest walk of the wave, and inside a hop the lanes whose cell is empty wait for the fullest cell.
+// Here every lane of the wave takes part, in two roles:
+//  * WALKERS.  The W rays that need a walk are numbered and each is given L = 8, 4, 2 or 1 ADJACENT lanes
+//    (the largest power of two with W * L <= 64; origin / direction / range go through LDS), lane s of the
+//    L walking the s-th L-th of the ray's parameter range inside the grid (a 3D-DDA entered at the start of
+//    the segment).  A walker does not test the spheres of its cell: it pushes (walker lane, sphere) pairs
+//    onto a queue of the wave in LDS, at most kPushPerRound per round.
+//  * TESTERS.  Whenever the queue holds a wave's worth of pairs (or no walker is left) all 64 lanes take one
+//    pair each, fetch the pair's ray from its walker's registers (ds_bpermute), run the reference's test
+//    (:244-258) and fold a hit into the ray's slot with one 64-bit LDS atomic minimum on (t bits, index):
+//    smallest t, lowest index among equal t -- the reference's closest-hit rule (Renderer.cpp:266), which
+//    does not depend on the order of the tests.
+// A walker stops once its ray's slot holds a hit before the exit of its cell by a clear margin (any
+// segment's hit counts), at the end of its segment, or outside the grid.  A hit whose point lies in a
+// segment is found through that segment's cells, because the sphere is listed in the cell that holds the
+// point; pairs pushed beyond that are tested all the same and can only lose.  So the set of tests is a
+// superset of what the lane-per-ray walk needs and the result is the linear scan's.
 // ---------------------------------------------------------------------------------
-constexpr uint32_t kCoopSlotsPerWave = 64u + 16u;              // float4 slots: 32 rays x 2, then 32 results x 8 B
+constexpr uint32_t kPushPerRound = 2u;
+constexpr uint32_t kQueueSlots = 64u + 64u * kPushPerRound;    // fewer than 64 pairs stay behind a drain
+// per wave, in float4 slots: 32 rays x 2, then 64 keys x 8 B, then the queue
+constexpr uint32_t kCoopSlotsPerWave = 64u + 32u + kQueueSlots / 4u;
 LUMA_DEV uint32_t lane_of_wave() { return threadIdx.x & 63u; }
 
 struct CoopLds {
-    float4* ray;        // per wave: 32 x 2 float4: (origin.xyz, t0), (dir.xyz, t1)
-    uint2*  res;        // per wave: 32 x (t bits, index)
+    float4* ray;                    // per wave: 32 x 2 float4: (origin.xyz, t0), (dir.xyz, t1)
+    unsigned long long* key;        // per wave: 64 x ((t bits << 32) | index), the best hit of ray slot q
+    uint32_t* queue;                // per wave: kQueueSlots x ((walker lane << 16 | 0) ... see pack below)
 };
+
+LUMA_DEV void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 template <bool RES>
 LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds_cells, const uint16_t* __restrict__ lds_items,
                              const float4* __restrict__ rec_gen, const CoopLds X, uint32_t lane, bool want, f3 origin, f3 dir,
                              int& idx_out, float& t_out, uint32_t& n_tests)
 {
-    float best_t = FLT_MAX;
-    uint32_t best = 0xFFFFFFFFu;
-    // the reference's test (:244-258) for the ray (o, d) with a = dot(d, d); winner by (t, index)
-    auto test = [&](uint32_t i, f3 o, f3 d, float a) {
+    constexpr uint32_t kNone = 0xFFFFFFFFu;
+    const uint32_t kMissT = __builtin_bit_cast(uint32_t, FLT_MAX);
+    // the reference's test (:244-258) for the ray (o, d) with a = dot(d, d); a hit is returned as a key
+    auto test = [&](uint32_t i, f3 o, f3 d, float a, unsigned long long& key) {
         const float4 s = rec_gen[i];
         const f3 diff = sub3(o, mk3(s.x, s.y, s.z));             // :244
         const float b = dot3(diff, d);
@@ -911,18 +937,25 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
         const float dd = fma_(b, b, -(a * c));
         if (LUMA_DBG_WALK == 0) { n_tests++; }
         if (LUMA_DBG_WALK == 3) { LUMA_WAVE_ONCE(n_tests); }
+        key = ~0ull;
         if (dd > 0.0f && b < 0.0f) {                             // :253
             const float t = (-b - sqrt_rn(dd)) / a;              // :255
-            if (t > 0.0f && (t < best_t || (t == best_t && i < best))) { best_t = t; best = i; }   // :258, :266
+            // :258 with best_t = FLT_MAX at the start: only 0 < t < FLT_MAX can ever win; such a t orders like its bits
+            if (t > 0.0f && t < FLT_MAX) { key = ((unsigned long long)__builtin_bit_cast(uint32_t, t) << 32) | i; }
         }
     };
 
     // ---- own ray: the always-tested spheres, and the part of the ray inside the grid's box ----
     const float a_own = dot3(dir, dir);
+    unsigned long long own = ((unsigned long long)kMissT << 32) | kNone;
     float t0 = 0.0f, t1 = FLT_MAX;
     bool inside = want;
     if (want) {
-        for (uint32_t j = 0; j < G.n_large; j++) { test(G.large[j], origin, dir, a_own); }
+        for (uint32_t j = 0; j < G.n_large; j++) {
+            unsigned long long key;
+            test(G.large[j], origin, dir, a_own, key);
+            own = key < own ? key : own;                         // :258, :266
+        }
         auto clip = [&](float o, float d, float org, uint32_t dim) {
             const float lo = org, hi = org + (float)dim * G.h;
             if (d != 0.0f) {
@@ -939,50 +972,46 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
         clip(origin.z, dir.z, G.org[2], G.dims[2]);
     }
     const bool walk = inside && t0 <= t1 && a_own > 0.0f;
-    const float own_t = best_t;
-    const uint32_t own_i = best;
 
     // ---- hand the rays out: rank r of the W walking rays goes to lanes [r * L, (r + 1) * L) ----
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(walk);
     const uint32_t W = (uint32_t)__builtin_popcountll(mask);
-    idx_out = (int)own_i;
-    t_out = own_t;
-    if (W == 0u) { return; }                                     // wave uniform
-    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-    const uint32_t L = W <= 8u ? 8u : W <= 16u ? 4u : W <= 32u ? 2u : 1u;   // wave uniform
-    uint32_t q = lane, seg = 0u;
-    bool have = walk;
-    f3 o = origin, d = dir;
-    float r_t0 = t0, r_t1 = t1;
-    if (L > 1u) {                                                // more than 32 rays: every lane walks its own
-        if (walk) {
-            X.ray[2u * rank] = make_float4(origin.x, origin.y, origin.z, t0);
-            X.ray[2u * rank + 1u] = make_float4(dir.x, dir.y, dir.z, t1);
+    if (W != 0u) {                                               // wave uniform
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+        const uint32_t logL = W <= 8u ? 3u : W <= 16u ? 2u : W <= 32u ? 1u : 0u;   // wave uniform
+        const uint32_t L = 1u << logL;
+        uint32_t q = lane, seg = 0u;                             // ray slot, segment
+        bool have = walk;
+        f3 o = origin, d = dir;
+        float r_t0 = t0, r_t1 = t1;
+        X.key[lane] = ((unsigned long long)kMissT << 32) | kNone;
+        if (logL) {                                              // (more than 32 rays: every lane walks its own)
+            if (walk) {
+                X.ray[2u * rank] = make_float4(origin.x, origin.y, origin.z, t0);
+                X.ray[2u * rank + 1u] = make_float4(dir.x, dir.y, dir.z, t1);
+            }
+            wave_lds_sync();
+            q = lane >> logL;
+            seg = lane & (L - 1u);
+            have = q < W;
+            if (have) {
+                const float4 r0 = X.ray[2u * q], r1 = X.ray[2u * q + 1u];
+                o = mk3(r0.x, r0.y, r0.z);
+                d = mk3(r1.x, r1.y, r1.z);
+                r_t0 = r0.w;
+                r_t1 = r1.w;
+            }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        q = lane / L;
-        seg = lane % L;
-        have = q < W;
-        if (have) {
-            const float4 r0 = X.ray[2u * q], r1 = X.ray[2u * q + 1u];
-            o = mk3(r0.x, r0.y, r0.z);
-            d = mk3(r1.x, r1.y, r1.z);
-            r_t0 = r0.w;
-            r_t1 = r1.w;
-        }
-    }
-
-    best_t = FLT_MAX;
-    best = 0xFFFFFFFFu;
-    // this lane's share of [t0, t1]; a range too long to cut (t1 overflowed) goes to the first lane whole
-    const float span = (r_t1 - r_t0) / (float)L;
-    const bool cut = span < FLT_MAX;
-    const float ts = (cut && seg > 0u) ? fma_(span, (float)seg, r_t0) : r_t0;
-    const float te = (cut && seg + 1u < L) ? fma_(span, (float)(seg + 1u), r_t0) : r_t1;
-    if (have && (cut || seg == 0u)) {
         const float a = dot3(d, d);
+
+        // this lane's share of [t0, t1]; a range too long to cut (t1 overflowed) goes to the first lane whole
+        const float span = (r_t1 - r_t0) / (float)L;
+        const bool cut = span < FLT_MAX;
+        const float ts = (cut && seg > 0u) ? fma_(span, (float)seg, r_t0) : r_t0;
+        const float te = (cut && seg + 1u < L) ? fma_(span, (float)(seg + 1u), r_t0) : r_t1;
+        bool walking = have && (cut || seg == 0u);
+
+        // enter the grid at ts (3D-DDA state; per-axis scalars: no indexed registers)
         float t_cell = FLT_MAX;                                  // time to cross one cell along the fastest axis
         auto enter = [&](float oc, float dc, float org, uint32_t dim, int& cell, float& t_next, float& inv) {
             const float p = fma_(dc, ts, oc);
@@ -996,61 +1025,99 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
                 t_next = FLT_MAX;
             }
         };
-        int cx, cy, cz;
-        float tx, ty, tz, ix, iy, iz;
-        enter(o.x, d.x, G.org[0], G.dims[0], cx, tx, ix);
-        enter(o.y, d.y, G.org[1], G.dims[1], cy, ty, iy);
-        enter(o.z, d.z, G.org[2], G.dims[2], cz, tz, iz);
-        const float margin = 1e-3f * t_cell;
-        const uint32_t most = G.dims[0] + G.dims[1] + G.dims[2] + 3u;    // a straight line crosses no more cells
-        for (uint32_t hop = 0; hop < most; hop++) {
-            if (LUMA_DBG_WALK == 1) { n_tests++; }
-            if (LUMA_DBG_WALK == 2) { LUMA_WAVE_ONCE(n_tests); }
+        int cx = 0, cy = 0, cz = 0;
+        float tx = FLT_MAX, ty = FLT_MAX, tz = FLT_MAX, ix = 0.f, iy = 0.f, iz = 0.f;
+        uint32_t k0 = 0, k1 = 0;
+        auto lookup = [&]() {
             const uint32_t id = ((uint32_t)cz * G.dims[1] + (uint32_t)cy) * G.dims[0] + (uint32_t)cx;
-            uint32_t k0, k1;
             if (RES || lds_cells) { k0 = lds_cells[id]; k1 = lds_cells[id + 1]; }
             else                  { k0 = G.cell_start[id]; k1 = G.cell_start[id + 1]; }
-            for (uint32_t k = k0; k < k1; k++) { test(RES ? (uint32_t)lds_items[k] : G.items[k], o, d, a); }
-            const float t_exit = __builtin_fminf(__builtin_fminf(tx, ty), tz);
-            if (best_t < t_exit - margin || t_exit > te + margin) { break; }
-            if (tx <= ty && tx <= tz) {
-                cx += d.x > 0.0f ? 1 : -1;
-                if (cx < 0 || cx >= (int)G.dims[0]) { break; }
-                tx = (G.org[0] + (float)(cx + (d.x > 0.0f ? 1 : 0)) * G.h - o.x) * ix;
-            } else if (ty <= tz) {
-                cy += d.y > 0.0f ? 1 : -1;
-                if (cy < 0 || cy >= (int)G.dims[1]) { break; }
-                ty = (G.org[1] + (float)(cy + (d.y > 0.0f ? 1 : 0)) * G.h - o.y) * iy;
-            } else {
-                cz += d.z > 0.0f ? 1 : -1;
-                if (cz < 0 || cz >= (int)G.dims[2]) { break; }
-                tz = (G.org[2] + (float)(cz + (d.z > 0.0f ? 1 : 0)) * G.h - o.z) * iz;
+        };
+        if (walking) {
+            enter(o.x, d.x, G.org[0], G.dims[0], cx, tx, ix);
+            enter(o.y, d.y, G.org[1], G.dims[1], cy, ty, iy);
+            enter(o.z, d.z, G.org[2], G.dims[2], cz, tz, iz);
+            lookup();
+        }
+        const float margin = 1e-3f * t_cell;
+        uint32_t hops_left = G.dims[0] + G.dims[1] + G.dims[2] + 3u;     // a straight line crosses no more cells
+        uint32_t queued = 0;                                     // wave uniform
+
+        for (;;) {
+            // ---- walkers: push up to kPushPerRound spheres of the current cell ----
+            const uint32_t c = walking ? min(k1 - k0, kPushPerRound) : 0u;
+            if (LUMA_DBG_WALK == 1 && walking) { n_tests++; }
+            if (LUMA_DBG_WALK == 2) { n_tests += lane == 0u ? 1u : 0u; }
+#pragma unroll
+            for (uint32_t j = 0; j < kPushPerRound; j++) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(c > j);
+                if (c > j) {
+                    const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    const uint32_t i = RES ? (uint32_t)lds_items[k0 + j] : G.items[k0 + j];
+                    X.queue[at] = RES ? ((lane << 16) | i) : i;
+                    if (!RES) { X.queue[kQueueSlots + at] = lane; }
+                }
+                queued += (uint32_t)__builtin_popcountll(m);
+            }
+            k0 += c;
+            const bool any = __builtin_amdgcn_ballot_w64(walking) != 0ull;
+
+            // ---- testers: one pair per lane while a wave's worth is queued, or everything once the walkers are done ----
+            while (queued >= 64u || (!any && queued > 0u)) {
+                wave_lds_sync();
+                const uint32_t take = min(queued, 64u), base = queued - take;
+                uint32_t owner = lane, i = 0;
+                if (lane < take) {
+                    const uint32_t pr = X.queue[base + lane];
+                    if (RES) { owner = pr >> 16; i = pr & 0xFFFFu; }
+                    else     { owner = X.queue[kQueueSlots + base + lane]; i = pr; }
+                }
+                const f3 po = mk3(__shfl(o.x, (int)owner, 64), __shfl(o.y, (int)owner, 64), __shfl(o.z, (int)owner, 64));
+                const f3 pd = mk3(__shfl(d.x, (int)owner, 64), __shfl(d.y, (int)owner, 64), __shfl(d.z, (int)owner, 64));
+                const float pa = __shfl(a, (int)owner, 64);
+                if (lane < take) {
+                    unsigned long long key;
+                    test(i, po, pd, pa, key);
+                    if (key != ~0ull) { atomicMin(&X.key[owner >> logL], key); }
+                }
+                queued = base;
+                wave_lds_sync();
+            }
+            if (!any) { break; }                                 // wave uniform; the queue is empty here
+
+            // ---- walkers whose cell is used up: stop, or cross the nearest face (one per hop when two are due at once) ----
+            if (walking && k0 == k1) {
+                const float best_t = __builtin_bit_cast(float, (uint32_t)(X.key[q] >> 32));
+                const float t_exit = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+                if (best_t < t_exit - margin || t_exit > te + margin || --hops_left == 0u) {
+                    walking = false;
+                } else {
+                    if (tx <= ty && tx <= tz) {
+                        cx += d.x > 0.0f ? 1 : -1;
+                        walking = cx >= 0 && cx < (int)G.dims[0];
+                        tx = (G.org[0] + (float)(cx + (d.x > 0.0f ? 1 : 0)) * G.h - o.x) * ix;
+                    } else if (ty <= tz) {
+                        cy += d.y > 0.0f ? 1 : -1;
+                        walking = cy >= 0 && cy < (int)G.dims[1];
+                        ty = (G.org[1] + (float)(cy + (d.y > 0.0f ? 1 : 0)) * G.h - o.y) * iy;
+                    } else {
+                        cz += d.z > 0.0f ? 1 : -1;
+                        walking = cz >= 0 && cz < (int)G.dims[2];
+                        tz = (G.org[2] + (float)(cz + (d.z > 0.0f ? 1 : 0)) * G.h - o.z) * iz;
+                    }
+                    if (walking) { lookup(); }
+                }
             }
         }
-    }
 
-    // ---- fold the L lanes of each ray: smallest t, lowest index among equal t ----
-    uint32_t bt = __builtin_bit_cast(uint32_t, best_t), bi = best;   // t > 0: its bit pattern orders like its value
-    for (uint32_t off = 1u; off < L; off <<= 1) {
-        const uint32_t ot = (uint32_t)__shfl_xor((int)bt, (int)off, 64), oi = (uint32_t)__shfl_xor((int)bi, (int)off, 64);
-        if (ot < bt || (ot == bt && oi < bi)) { bt = ot; bi = oi; }
+        // ---- back to the rays' own lanes ----
+        if (walk) {
+            const unsigned long long found = X.key[logL ? rank : lane];
+            own = found < own ? found : own;
+        }
     }
-    uint2 r = make_uint2(bt, bi);
-    if (L > 1u) {
-        if (have && seg == 0u) { X.res[q] = r; }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (walk) { r = X.res[rank]; }
-    }
-    if (walk) {
-        const float rt = __builtin_bit_cast(float, r.x);
-        float ft = own_t;
-        uint32_t fi = own_i;
-        if (r.y != 0xFFFFFFFFu && (rt < ft || (rt == ft && r.y < fi))) { ft = rt; fi = r.y; }
-        idx_out = (int)fi;
-        t_out = ft;
-    }
+    idx_out = (int)(uint32_t)own;                                // kNone reads as -1
+    t_out = __builtin_bit_cast(float, (uint32_t)(own >> 32));
 }
 
 template <int TILE_W, int WAVES, bool NOISE, bool FROM_HIT, bool GRID = false, bool RES = false>
@@ -1069,7 +1136,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     const float4* rec_gen = lds_rec + n_pad;
     const uint16_t* grid_cells = nullptr;
     const uint16_t* grid_items = nullptr;
-    CoopLds xch = { nullptr, nullptr };
+    CoopLds xch = { nullptr, nullptr, nullptr };
     if (GRID) {
         rec_cam = A.records;
         rec_gen = A.records + n;
@@ -1092,9 +1159,10 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
             grid_items = stage;
             next += (A.grid.n_items + 7u) / 8u;
         }
-        float4* mine = next + (threadIdx.x >> 6) * kCoopSlotsPerWave;
+        float4* mine = next + (threadIdx.x >> 6) * (RES ? kCoopSlotsPerWave : kCoopSlotsPerWave + kQueueSlots / 4u);
         xch.ray = mine;
-        xch.res = reinterpret_cast<uint2*>(mine + 64);
+        xch.key = reinterpret_cast<unsigned long long*>(mine + 64);
+        xch.queue = reinterpret_cast<uint32_t*>(mine + 96);     // !RES: a second plane of kQueueSlots words holds the walker lanes
         __syncthreads();
     } else {
         const float qnan = __builtin_nanf("");
@@ -1113,7 +1181,9 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         if (GRID) {
             idx = -1;
             t = FLT_MAX;
-            if (want) { idx = scan_view(A.grid, rec_cam, d, t, ntests); }    // direction grid: no walk, one lane per ray
+            if (want) {                                          // direction grid: no walk, one lane per ray
+                idx = RES ? scan_view<true>(A.grid, rec_gen, o, d, t, ntests) : scan_view<false>(A.grid, rec_cam, o, d, t, ntests);
+            }
         } else {
             wave_scan<true>(rec_cam, n_pad, lane_of_wave(), want, o, d, idx, t);
         }
@@ -1442,10 +1512,11 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         // with the cell offsets only (<= 26 KiB), when refresh_grid found those small enough
         const GridArgs& g = args.grid;
         const size_t res_slots = (size_t)n + (g.n_cells + 7u) / 8u + (g.n_items + 7u) / 8u + 16u * kCoopSlotsPerWave;
+        const size_t wave_slots = kCoopSlotsPerWave + kQueueSlots / 4u;   // !resident: sphere indices need whole words
         const bool resident = n < 65536u && g.n_items < 65536u && res_slots * sizeof(float4) <= 156u * 1024u;
         waves = resident ? 16 : 8;
         lds = resident ? res_slots * sizeof(float4)
-                       : ((((size_t)g.lds_cells + 7u) / 8u) + (size_t)waves * kCoopSlotsPerWave) * sizeof(float4);
+                       : ((((size_t)g.lds_cells + 7u) / 8u) + (size_t)waves * wave_slots) * sizeof(float4);
 #define LUMA_COOP(W, R) { { render_kernel_sp<kTileW, W, false, false, true, R>, render_kernel_sp<kTileW, W, false, true, true, R> }, \
                           { render_kernel_sp<kTileW, W, true, false, true, R>,  render_kernel_sp<kTileW, W, true, true, true, R> } }
         static const kernel_t coop_table[2][2][2] = { LUMA_COOP(8, false), LUMA_COOP(16, true) };
