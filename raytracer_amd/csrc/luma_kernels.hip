@@ -903,6 +903,7 @@ LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t
 // superset of what the lane-per-ray walk needs and the result is the linear scan's.
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kPushPerRound = 2u;
+constexpr uint32_t kHopsPerRound = 1u;
 constexpr uint32_t kQueueSlots = 64u + 64u * kPushPerRound;    // fewer than 64 pairs stay behind a drain
 // per wave, in float4 slots: 32 rays x 2, then 64 keys x 8 B, then the queue
 constexpr uint32_t kCoopSlotsPerWave = 64u + 32u + kQueueSlots / 4u;
@@ -1042,8 +1043,38 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
         const float margin = 1e-3f * t_cell;
         uint32_t hops_left = G.dims[0] + G.dims[1] + G.dims[2] + 3u;     // a straight line crosses no more cells
         uint32_t queued = 0;                                     // wave uniform
+        const int step_x = d.x > 0.0f ? 1 : -1, step_y = d.y > 0.0f ? 1 : -1, step_z = d.z > 0.0f ? 1 : -1;
+        // face crossed after the step to cell c along an axis: t = (org + (c + (d > 0)) * h - o) / d
+        const float face_x = G.org[0] + (d.x > 0.0f ? G.h : 0.0f) - o.x;
+        const float face_y = G.org[1] + (d.y > 0.0f ? G.h : 0.0f) - o.y;
+        const float face_z = G.org[2] + (d.z > 0.0f ? G.h : 0.0f) - o.z;
 
         for (;;) {
+            // ---- walkers whose cell is used up: stop, or cross faces (the nearest; one per hop when two are due at
+            //      at once) until a cell lists something, at most kHopsPerRound a round.  Branch free: the lanes of
+            //      a wave cross different faces.  (The crossing times only steer the walk and its margins; the
+            //      tests' arithmetic is untouched by how they are rounded.)
+            if (walking && k0 == k1) {
+                const float best_t = __builtin_bit_cast(float, (uint32_t)(X.key[q] >> 32));
+                for (uint32_t hop = 0; hop < kHopsPerRound; hop++) {
+                    const float t_exit = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+                    if (best_t < t_exit - margin || t_exit > te + margin || --hops_left == 0u) { walking = false; break; }
+                    const bool mx = tx <= ty && tx <= tz, my = !mx && ty <= tz, mz = !mx && !my;
+                    cx += mx ? step_x : 0;
+                    cy += my ? step_y : 0;
+                    cz += mz ? step_z : 0;
+                    const int cm = mx ? cx : my ? cy : cz;
+                    const uint32_t dim = mx ? G.dims[0] : my ? G.dims[1] : G.dims[2];
+                    if ((uint32_t)cm >= dim) { walking = false; break; }
+                    const float t_new = fma_((float)cm, G.h, mx ? face_x : my ? face_y : face_z) * (mx ? ix : my ? iy : iz);
+                    tx = mx ? t_new : tx;
+                    ty = my ? t_new : ty;
+                    tz = mz ? t_new : tz;
+                    lookup();
+                    if (k0 != k1) { break; }
+                }
+            }
+
             // ---- walkers: push up to kPushPerRound spheres of the current cell ----
             const uint32_t c = walking ? min(k1 - k0, kPushPerRound) : 0u;
             if (LUMA_DBG_WALK == 1 && walking) { n_tests++; }
@@ -1084,30 +1115,6 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
                 wave_lds_sync();
             }
             if (!any) { break; }                                 // wave uniform; the queue is empty here
-
-            // ---- walkers whose cell is used up: stop, or cross the nearest face (one per hop when two are due at once) ----
-            if (walking && k0 == k1) {
-                const float best_t = __builtin_bit_cast(float, (uint32_t)(X.key[q] >> 32));
-                const float t_exit = __builtin_fminf(__builtin_fminf(tx, ty), tz);
-                if (best_t < t_exit - margin || t_exit > te + margin || --hops_left == 0u) {
-                    walking = false;
-                } else {
-                    if (tx <= ty && tx <= tz) {
-                        cx += d.x > 0.0f ? 1 : -1;
-                        walking = cx >= 0 && cx < (int)G.dims[0];
-                        tx = (G.org[0] + (float)(cx + (d.x > 0.0f ? 1 : 0)) * G.h - o.x) * ix;
-                    } else if (ty <= tz) {
-                        cy += d.y > 0.0f ? 1 : -1;
-                        walking = cy >= 0 && cy < (int)G.dims[1];
-                        ty = (G.org[1] + (float)(cy + (d.y > 0.0f ? 1 : 0)) * G.h - o.y) * iy;
-                    } else {
-                        cz += d.z > 0.0f ? 1 : -1;
-                        walking = cz >= 0 && cz < (int)G.dims[2];
-                        tz = (G.org[2] + (float)(cz + (d.z > 0.0f ? 1 : 0)) * G.h - o.z) * iz;
-                    }
-                    if (walking) { lookup(); }
-                }
-            }
         }
 
         // ---- back to the rays' own lanes ----
