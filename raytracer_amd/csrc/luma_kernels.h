@@ -25,11 +25,14 @@ static constexpr size_t kMaxSceneLdsBytes = 158 * 1024;
 // sphere-parallel scan (render_kernel_sp); smaller ones the ray-per-lane scan.
 static constexpr uint32_t kSphereParallelMin = 320;   // measured crossover (tools/scene_size_sweep.py)
 
+// FLAG_GRID: scenes with at least this many spheres walk the grid wave-cooperatively (wave_grid_walk).
+static constexpr uint32_t kGridWaveWalkMin = 512;
+
 // The ray counter is kCounterSlots 64-bit slots, one per 64-byte line (stride in u64).
 static constexpr uint32_t kCounterSlots = 256;
 static constexpr uint32_t kCounterStride = 8;
 
-// Uniform grid over the spheres (luma_grid.h), used by the ray-per-lane kernel under FLAG_GRID.
+// Uniform grid over the spheres (luma_grid.h), used under FLAG_GRID.
 struct GridArgs {
     uint32_t dims[3];
     float    org[3];

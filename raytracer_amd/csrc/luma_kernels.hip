@@ -17,7 +17,6 @@
 #include <hip/hip_runtime.h>
 #include <float.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include <algorithm>
 #include <mutex>
@@ -1424,11 +1423,14 @@ bool sphere_parallel_scene(uint32_t n_spheres)
         && (size_t)((n_spheres + 63u) & ~63u) * 2u * sizeof(float4) <= kMaxSceneLdsBytes;
 }
 
-// FLAG_GRID launches whose rays from hit points walk the grid as a wave (wave_grid_walk)
+// FLAG_GRID launches whose rays from hit points walk the grid as a wave (render_kernel_sp<GRID>, wave_grid_walk)
+// instead of lane by lane (render_kernel<GRID>).  Measured on MI355X, 1080p x 16 spp, lane / wave kernel ms
+// (tools/grid_coop_sweep.py): 64 spheres 1.73 / 1.92, 320: 2.55 / 2.53, 1024: 3.77 / 2.93, 4096: 5.98 / 4.02,
+// 16384: 10.3 / 8.3, 262144: 12.6 / 11.4; at 2 spp the wave kernel's fixed cost (one resident set of large
+// workgroups) still shows at 320: 0.48 / 0.54.
 bool grid_wave_walk(uint32_t n_spheres)
 {
-    static const bool on = [] { const char* e = getenv("LUMA_GRID_COOP"); return e && *e == '1'; }();
-    return on && n_spheres > 0;
+    return n_spheres >= kGridWaveWalkMin;
 }
 
 // Launches that hand out wave tiles through RenderArgs::tile_counter (it must be zero at the start)

@@ -305,6 +305,10 @@ def test_synthetic_scene(abi, oracle, n, W, H, spp, flags, paths):
 @pytest.mark.parametrize("n,W,H,spp,flags,posed", [
     (5, 160, 90, 3, 0, False), (2, 64, 36, 2, 0, False), (64, 96, 54, 2, 2, False), (300, 96, 54, 2, 0, True),
     (1000, 64, 36, 2, 1, False), (4096, 96, 54, 1, 0, False), (4096, 48, 27, 2, 2, True), (20000, 64, 36, 1, 0, False),
+    # the wave-cooperative walk (512 spheres and up): at its threshold, LDS resident with rays from hit points as
+    # bounce rays (flag 2) and without noise (flag 1), and too large for LDS (tables in global memory) likewise
+    (511, 64, 36, 2, 0, False), (512, 64, 36, 2, 0, False), (2500, 80, 45, 3, 3, True), (4500, 64, 36, 2, 2, False),
+    (20000, 48, 27, 2, 2, True), (9000, 64, 36, 2, 1, True), (70000, 48, 27, 1, 2, False),
 ])
 def test_grid_gives_the_linear_scan_frame(abi, oracle, n, W, H, spp, flags, posed):
     """LUMA_FLAG_GRID: rays are tested only against the spheres of the grid cells they cross (plus

@@ -1,7 +1,7 @@
 """Walk statistics of the LUMA_FLAG_GRID kernels on one of config #5's eight bands, from debug builds of the
 library (-DLUMA_DBG_WALK=1|2|3, see luma_kernels.hip: the sphere-test counter then holds 1: hops summed over
 lanes, 2: hop-loop trips per wave, 3: test-body trips per wave, for the rays from hit points only).
-Usage on the GPU box, from the repo root:  LUMA_HIP_LIB=$PWD/ab/dbgN.so [LUMA_GRID_COOP=1] python tools/grid_walk_stats.py"""
+Usage on the GPU box, from the repo root:  LUMA_HIP_LIB=$PWD/ab/dbgN.so python tools/grid_walk_stats.py"""
 import os, sys; sys.path.insert(0, '.')
 from raytracer_amd import abi
 W, H = 7680, 4320
@@ -14,7 +14,6 @@ with abi.Context(0) as ctx:
         ctx.render_device(p, want_stats=True)
         st = ctx.render_device(p, want_stats=True)
         rays[name] = st.rays
-        print("%s lib=%s coop=%s  %-8s %8.3f ms  rays %d  counter %d" % (
-            os.path.basename(os.environ.get("LUMA_HIP_LIB", "libluma_hip.so")), "", os.environ.get("LUMA_GRID_COOP", "0"),
-            name, st.kernel_ms, st.rays, st.sphere_tests), flush=True)
+        print("%-14s %-8s %8.3f ms  rays %d  counter %d" % (
+            os.path.basename(os.environ.get("LUMA_HIP_LIB", "libluma_hip.so")), name, st.kernel_ms, st.rays, st.sphere_tests), flush=True)
     print("indirect rays: %d" % (rays["paths=1"] - rays["paths=0"]))
