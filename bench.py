@@ -299,8 +299,11 @@ def main():
         def whole_frame():
             ctx.render_device(params, band.data_ptr(), stream.cuda_stream)
             send = band.cpu() if rehearsal else band
-            full = (bands.gather_striped(send, HEIGHT, WIDTH, rank, world, stripe) if stripe
-                    else bands.gather_frame(send, HEIGHT, WIDTH, rank, world))
+            if a.emulate_world:      # one band of an emulated split: the gather moves just that band
+                full = bands.gather_frame(send, (y1 - y0) * world, WIDTH, rank, world)
+            else:
+                full = (bands.gather_striped(send, HEIGHT, WIDTH, rank, world, stripe) if stripe
+                        else bands.gather_frame(send, HEIGHT, WIDTH, rank, world))
             if host is not None and full is not None and full.numel() == host.numel():
                 host.copy_(full.reshape(HEIGHT, WIDTH), non_blocking=True)
             torch.cuda.synchronize()
