@@ -931,7 +931,7 @@ LUMA_DEV void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool RES>
+template <bool RES>   // RES: cell offsets and cell lists in LDS as 16-bit words (sphere indices below 65536)
 LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds_cells, const uint16_t* __restrict__ lds_items,
                              const float4* __restrict__ rec_gen, const CoopLds X, uint32_t lane, bool want, f3 origin, f3 dir,
                              int& idx_out, float& t_out, uint32_t& n_tests)
@@ -1136,7 +1136,7 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
     t_out = __builtin_bit_cast(float, (uint32_t)(own >> 32));
 }
 
-template <int TILE_W, int WAVES, bool NOISE, bool FROM_HIT, bool GRID = false, bool RES = false>
+template <int TILE_W, int WAVES, bool NOISE, bool FROM_HIT, bool GRID = false, int RES = 0>
 __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs A)
 {
     // [0,n_pad): camera-origin records; [n_pad,2 n_pad): general records; padding = NaN
@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         rec_cam = A.records;
         rec_gen = A.records + n;
         float4* next = lds_rec;
-        if (RES) {
+        if (RES == 2) {
             for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) { next[i] = A.records[n + i]; }
             rec_gen = next;
             next += n;
@@ -1198,14 +1198,14 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
             idx = -1;
             t = FLT_MAX;
             if (want) {                                          // direction grid: no walk, one lane per ray
-                idx = RES ? scan_view<true>(A.grid, rec_gen, o, d, t, ntests) : scan_view<false>(A.grid, rec_cam, o, d, t, ntests);
+                idx = RES == 2 ? scan_view<true>(A.grid, rec_gen, o, d, t, ntests) : scan_view<false>(A.grid, rec_cam, o, d, t, ntests);
             }
         } else {
             wave_scan<true>(rec_cam, n_pad, lane_of_wave(), want, o, d, idx, t);
         }
     };
     auto scan_gen = [&](bool want, f3 o, f3 d, int& idx, float& t) {
-        if (GRID) { wave_grid_walk<RES>(A.grid, grid_cells, grid_items, rec_gen, xch, lane_of_wave(), want, o, d, idx, t, ntests); }
+        if (GRID) { wave_grid_walk<(RES != 0)>(A.grid, grid_cells, grid_items, rec_gen, xch, lane_of_wave(), want, o, d, idx, t, ntests); }
         else      { wave_scan<false>(rec_gen, n_pad, lane_of_wave(), want, o, d, idx, t); }
     };
 
@@ -1530,15 +1530,17 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         // LDS when they fit beside the waves' exchange areas -- one 16-wave workgroup per CU; else 8-wave workgroups
         // with the cell offsets only (<= 26 KiB), when refresh_grid found those small enough
         const GridArgs& g = args.grid;
-        const size_t res_slots = (size_t)n + (g.n_cells + 7u) / 8u + (g.n_items + 7u) / 8u + 16u * kCoopSlotsPerWave;
-        const size_t wave_slots = kCoopSlotsPerWave + kQueueSlots / 4u;   // !resident: sphere indices need whole words
-        const bool resident = n < 65536u && g.n_items < 65536u && res_slots * sizeof(float4) <= 156u * 1024u;
+        const size_t table_slots = (g.n_cells + 7u) / 8u + (g.n_items + 7u) / 8u + 16u * kCoopSlotsPerWave;
+        const size_t wave_slots = kCoopSlotsPerWave + kQueueSlots / 4u;   // tables in global memory: sphere indices need whole words
+        const bool small_ids = n < 65536u && g.n_items < 65536u;
+        const int resident = !small_ids ? 0 : (table_slots + n) * sizeof(float4) <= 156u * 1024u ? 2
+                                            : table_slots * sizeof(float4) <= 156u * 1024u ? 1 : 0;
         waves = resident ? 16 : 8;
-        lds = resident ? res_slots * sizeof(float4)
+        lds = resident ? (table_slots + (resident == 2 ? n : 0u)) * sizeof(float4)
                        : ((((size_t)g.lds_cells + 7u) / 8u) + (size_t)waves * wave_slots) * sizeof(float4);
 #define LUMA_COOP(W, R) { { render_kernel_sp<kTileW, W, false, false, true, R>, render_kernel_sp<kTileW, W, false, true, true, R> }, \
                           { render_kernel_sp<kTileW, W, true, false, true, R>,  render_kernel_sp<kTileW, W, true, true, true, R> } }
-        static const kernel_t coop_table[2][2][2] = { LUMA_COOP(8, false), LUMA_COOP(16, true) };
+        static const kernel_t coop_table[3][2][2] = { LUMA_COOP(8, 0), LUMA_COOP(16, 1), LUMA_COOP(16, 2) };
 #undef LUMA_COOP
         k = coop_table[resident][noise][from_hit];
     } else if (sphere_parallel) {
