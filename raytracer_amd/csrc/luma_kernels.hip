@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 #include <float.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -402,14 +403,31 @@ LUMA_DEV int scan_grid(const GridArgs& G, const uint16_t* __restrict__ lds_cells
     return best;
 }
 
+// The grid arguments of the launch, read where they are used: a pointer into the kernel-argument segment that the
+// compiler cannot look through, so the ~30 scalars behind it are loaded (scalar loads, cached) inside the code that
+// needs them instead of sitting in SGPRs -- or worse, in spill lanes -- for the whole kernel.  RenderArgs is the
+// kernels' only argument, so it starts the segment.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) GridArgs* KernargGridPtr;
+LUMA_DEV KernargGridPtr kernarg_grid()
+{
+    auto p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (KernargGridPtr)(p + offsetof(RenderArgs, grid));
+}
+#else
+typedef const GridArgs* KernargGridPtr;
+LUMA_DEV KernargGridPtr kernarg_grid() { return nullptr; }
+#endif
+
 // Closest hit of a ray FROM camera.pos through the direction grid (FLAG_GRID; luma_grid.h
 // HostViewGrid): no walk at all, the ray's direction picks one bin of a cube map around camera.pos
 // and the bin lists every sphere such a ray can hit.  Same test, same (t, index) rule as scan_grid.
 // FROM_GEN: `rec` holds the general records (centre, radius) and the test derives the camera-origin record
 // from them with prepare_records_kernel's own arithmetic (the same bits), for kernels that keep only the
 // general records in LDS.
-template <bool FROM_GEN = false>
-LUMA_DEV int scan_view(const GridArgs& G, const float4* __restrict__ rec, f3 campos, f3 dir, float& t_out, uint32_t& n_tests)
+template <bool FROM_GEN = false, typename GridPtr = const GridArgs*>
+LUMA_DEV int scan_view(GridPtr G, const float4* __restrict__ rec, f3 campos, f3 dir, float& t_out, uint32_t& n_tests)
 {
     const float a = dot3(dir, dir);                              // :246
     float best_t = FLT_MAX;
@@ -428,7 +446,7 @@ LUMA_DEV int scan_view(const GridArgs& G, const float4* __restrict__ rec, f3 cam
             if (t > 0.0f && (t < best_t || (t == best_t && (int)i < best))) { best_t = t; best = (int)i; }   // :258, :266
         }
     };
-    for (uint32_t j = 0; j < G.n_view_large; j++) { test(G.view_large[j]); }
+    for (uint32_t j = 0; j < G->n_view_large; j++) { test(G->view_large[j]); }
 
     // face = 2 * major axis + (negative), u and v = the other two components over |major|; the bins
     // are padded by a whole bin on the host, so the approximate reciprocal is accurate enough
@@ -441,16 +459,16 @@ LUMA_DEV int scan_view(const GridArgs& G, const float4* __restrict__ rec, f3 cam
     if (a > 0.0f && a < __builtin_inff()) {                      // (a zero or non-finite direction hits nothing small)
         face += major < 0.0f ? 1u : 0u;
         const float inv = __builtin_amdgcn_rcpf(__builtin_fabsf(major));
-        const int last = (int)G.view_res - 1;
-        const int iu = min(max((int)__builtin_floorf(fma_(u * inv, G.view_half_res, G.view_half_res)), 0), last);
-        const int iv = min(max((int)__builtin_floorf(fma_(v * inv, G.view_half_res, G.view_half_res)), 0), last);
-        const uint32_t bin = (face * G.view_res + (uint32_t)iv) * G.view_res + (uint32_t)iu;
-        const uint32_t k1 = G.view_start[bin + 1];
+        const int last = (int)G->view_res - 1;
+        const int iu = min(max((int)__builtin_floorf(fma_(u * inv, G->view_half_res, G->view_half_res)), 0), last);
+        const int iv = min(max((int)__builtin_floorf(fma_(v * inv, G->view_half_res, G->view_half_res)), 0), last);
+        const uint32_t bin = (face * G->view_res + (uint32_t)iv) * G->view_res + (uint32_t)iu;
+        const uint32_t k1 = G->view_start[bin + 1];
         // the bin's spheres come nearest first: stop once the best hit is nearer than the rest can be
         // (distance = t * |dir|; 1e-3 of slack covers the approximate square root many times over)
         const float len = a * __builtin_amdgcn_rsqf(a) * 1.001f;
-        for (uint32_t k = G.view_start[bin]; k < k1; k++) {
-            const uint2 it = G.view_items[k];
+        for (uint32_t k = G->view_start[bin]; k < k1; k++) {
+            const uint2 it = G->view_items[k];
             if (best_t * len < __builtin_bit_cast(float, it.y)) { break; }
             test(it.x);
         }
@@ -575,7 +593,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     // Renderer::trace_ray (:234-287): linear scan, or the same tests through the grid
     auto closest_cam = [&](f3 o, f3 d, float& t) {
         if (GRID) {
-            if (A.grid.view_res) { return scan_view(A.grid, rec_cam, campos, d, t, ntests); }   // every such ray starts at camera.pos
+            if (A.grid.view_res) { return scan_view(&A.grid, rec_cam, campos, d, t, ntests); }   // every such ray starts at camera.pos
             return scan_grid<true>(A.grid, grid_cells, rec_cam, rec_gen, o, d, t, ntests);
         }
         // compile-time sphere count: the records come by scalar loads (s_load_dwordx4, one per sphere and scan,
@@ -931,8 +949,8 @@ LUMA_DEV void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool RES>   // RES: cell offsets and cell lists in LDS as 16-bit words (sphere indices below 65536)
-LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds_cells, const uint16_t* __restrict__ lds_items,
+template <bool RES, typename GridPtr>   // RES: cell offsets and cell lists in LDS as 16-bit words (sphere indices below 65536)
+LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, const uint16_t* __restrict__ lds_items,
                              const float4* __restrict__ rec_gen, const CoopLds X, uint32_t lane, bool want, f3 origin, f3 dir,
                              int& idx_out, float& t_out, uint32_t& n_tests)
 {
@@ -961,13 +979,13 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
     float t0 = 0.0f, t1 = FLT_MAX;
     bool inside = want;
     if (want) {
-        for (uint32_t j = 0; j < G.n_large; j++) {
+        for (uint32_t j = 0; j < G->n_large; j++) {
             unsigned long long key;
-            test(G.large[j], origin, dir, a_own, key);
+            test(G->large[j], origin, dir, a_own, key);
             own = key < own ? key : own;                         // :258, :266
         }
         auto clip = [&](float o, float d, float org, uint32_t dim) {
-            const float lo = org, hi = org + (float)dim * G.h;
+            const float lo = org, hi = org + (float)dim * G->h;
             if (d != 0.0f) {
                 const float inv = 1.0f / d;
                 const float ta = (lo - o) * inv, tb = (hi - o) * inv;
@@ -977,41 +995,50 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
                 inside = inside && (o >= lo && o <= hi);
             }
         };
-        clip(origin.x, dir.x, G.org[0], G.dims[0]);
-        clip(origin.y, dir.y, G.org[1], G.dims[1]);
-        clip(origin.z, dir.z, G.org[2], G.dims[2]);
+        clip(origin.x, dir.x, G->org[0], G->dims[0]);
+        clip(origin.y, dir.y, G->org[1], G->dims[1]);
+        clip(origin.z, dir.z, G->org[2], G->dims[2]);
     }
     const bool walk = inside && t0 <= t1 && a_own > 0.0f;
 
-    // ---- hand the rays out: rank r of the W walking rays goes to lanes [r * L, (r + 1) * L) ----
+    // ---- hand the rays out: every walking ray gets one lane, and the lanes left over are shared out in proportion
+    //      to the cells the rays may cross (their length inside the grid over the cell size, summed over the axes):
+    //      adjacent lanes [start, start + cnt) for a ray, lane s of them walks the s-th cnt-th of its range ----
     const unsigned long long mask = __builtin_amdgcn_ballot_w64(walk);
     const uint32_t W = (uint32_t)__builtin_popcountll(mask);
     if (W != 0u) {                                               // wave uniform
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-        const uint32_t logL = W <= 8u ? 3u : W <= 16u ? 2u : W <= 32u ? 1u : 0u;   // wave uniform
-        const uint32_t L = 1u << logL;
-        uint32_t q = lane, seg = 0u;                             // ray slot, segment
-        bool have = walk;
-        f3 o = origin, d = dir;
-        float r_t0 = t0, r_t1 = t1;
-        X.key[lane] = ((unsigned long long)kMissT << 32) | kNone;
-        if (logL) {                                              // (more than 32 rays: every lane walks its own)
-            if (walk) {
-                X.ray[2u * rank] = make_float4(origin.x, origin.y, origin.z, t0);
-                X.ray[2u * rank + 1u] = make_float4(dir.x, dir.y, dir.z, t1);
-            }
-            wave_lds_sync();
-            q = lane >> logL;
-            seg = lane & (L - 1u);
-            have = q < W;
-            if (have) {
-                const float4 r0 = X.ray[2u * q], r1 = X.ray[2u * q + 1u];
-                o = mk3(r0.x, r0.y, r0.z);
-                d = mk3(r1.x, r1.y, r1.z);
-                r_t0 = r0.w;
-                r_t1 = r1.w;
-            }
+        float est = (t1 - t0) * ((__builtin_fabsf(dir.x) + __builtin_fabsf(dir.y) + __builtin_fabsf(dir.z)) * G->inv_h);
+        est = walk ? __builtin_fminf(__builtin_fmaxf(est, 1.0f), 1024.0f) : 0.0f;   // (fmaxf drops a NaN)
+        float total = est;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { total += __shfl_xor(total, off, 64); }
+        // floor of a little less than the exact share: the shares never add up to more than the lanes left over
+        const uint32_t cnt = walk ? 1u + (uint32_t)(est * ((float)(64u - W) * 0.999f / total)) : 0u;
+        uint32_t start = cnt;                                    // inclusive prefix sum, then exclusive
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)start, off, 64);
+            start += lane >= (uint32_t)off ? up : 0u;
         }
+        start -= cnt;
+        // lane j finds its ray: owners mark the first lane of their run in a byte map, the marks' ballot gives every
+        // lane the start of its run, and the ray comes from the owner's registers (ds_bpermute)
+        uint8_t* const map = reinterpret_cast<uint8_t*>(X.ray);
+        map[lane] = 0;
+        wave_lds_sync();
+        if (walk) { map[start] = (uint8_t)(0x80u | lane); }
+        X.key[lane] = ((unsigned long long)kMissT << 32) | kNone;    // ray slot = the lane that owns the ray
+        wave_lds_sync();
+        const uint32_t mark = map[lane];
+        const unsigned long long heads = __builtin_amdgcn_ballot_w64(mark != 0u);   // bit 0 is always set (the first ray starts at 0)
+        const uint32_t head = 63u - (uint32_t)__builtin_clzll(heads & (~0ull >> (63u - lane)));
+        const int q = (int)((uint32_t)__shfl((int)mark, (int)head, 64) & 63u);      // the owner's lane = the ray's slot
+        const uint32_t seg = lane - head;
+        const uint32_t L = (uint32_t)__shfl((int)cnt, q, 64);
+        const bool have = seg < L;
+        const f3 o = mk3(__shfl(origin.x, q, 64), __shfl(origin.y, q, 64), __shfl(origin.z, q, 64));
+        const f3 d = mk3(__shfl(dir.x, q, 64), __shfl(dir.y, q, 64), __shfl(dir.z, q, 64));
+        const float r_t0 = __shfl(t0, q, 64), r_t1 = __shfl(t1, q, 64);
         const float a = dot3(d, d);
 
         // this lane's share of [t0, t1]; a range too long to cut (t1 overflowed) goes to the first lane whole
@@ -1025,11 +1052,11 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
         float t_cell = FLT_MAX;                                  // time to cross one cell along the fastest axis
         auto enter = [&](float oc, float dc, float org, uint32_t dim, int& cell, float& t_next, float& inv) {
             const float p = fma_(dc, ts, oc);
-            cell = min(max((int)__builtin_floorf((p - org) * G.inv_h), 0), (int)dim - 1);
+            cell = min(max((int)__builtin_floorf((p - org) * G->inv_h), 0), (int)dim - 1);
             if (dc != 0.0f) {
                 inv = 1.0f / dc;
-                t_next = (org + (float)(cell + (dc > 0.0f ? 1 : 0)) * G.h - oc) * inv;
-                t_cell = __builtin_fminf(t_cell, G.h * __builtin_fabsf(inv));
+                t_next = (org + (float)(cell + (dc > 0.0f ? 1 : 0)) * G->h - oc) * inv;
+                t_cell = __builtin_fminf(t_cell, G->h * __builtin_fabsf(inv));
             } else {
                 inv = 0.0f;
                 t_next = FLT_MAX;
@@ -1039,24 +1066,24 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
         float tx = FLT_MAX, ty = FLT_MAX, tz = FLT_MAX, ix = 0.f, iy = 0.f, iz = 0.f;
         uint32_t k0 = 0, k1 = 0;
         auto lookup = [&]() {
-            const uint32_t id = ((uint32_t)cz * G.dims[1] + (uint32_t)cy) * G.dims[0] + (uint32_t)cx;
+            const uint32_t id = ((uint32_t)cz * G->dims[1] + (uint32_t)cy) * G->dims[0] + (uint32_t)cx;
             if (RES || lds_cells) { k0 = lds_cells[id]; k1 = lds_cells[id + 1]; }
-            else                  { k0 = G.cell_start[id]; k1 = G.cell_start[id + 1]; }
+            else                  { k0 = G->cell_start[id]; k1 = G->cell_start[id + 1]; }
         };
         if (walking) {
-            enter(o.x, d.x, G.org[0], G.dims[0], cx, tx, ix);
-            enter(o.y, d.y, G.org[1], G.dims[1], cy, ty, iy);
-            enter(o.z, d.z, G.org[2], G.dims[2], cz, tz, iz);
+            enter(o.x, d.x, G->org[0], G->dims[0], cx, tx, ix);
+            enter(o.y, d.y, G->org[1], G->dims[1], cy, ty, iy);
+            enter(o.z, d.z, G->org[2], G->dims[2], cz, tz, iz);
             lookup();
         }
         const float margin = 1e-3f * t_cell;
-        uint32_t hops_left = G.dims[0] + G.dims[1] + G.dims[2] + 3u;     // a straight line crosses no more cells
+        uint32_t hops_left = G->dims[0] + G->dims[1] + G->dims[2] + 3u;     // a straight line crosses no more cells
         uint32_t queued = 0;                                     // wave uniform
         const int step_x = d.x > 0.0f ? 1 : -1, step_y = d.y > 0.0f ? 1 : -1, step_z = d.z > 0.0f ? 1 : -1;
         // face crossed after the step to cell c along an axis: t = (org + (c + (d > 0)) * h - o) / d
-        const float face_x = G.org[0] + (d.x > 0.0f ? G.h : 0.0f) - o.x;
-        const float face_y = G.org[1] + (d.y > 0.0f ? G.h : 0.0f) - o.y;
-        const float face_z = G.org[2] + (d.z > 0.0f ? G.h : 0.0f) - o.z;
+        const float face_x = G->org[0] + (d.x > 0.0f ? G->h : 0.0f) - o.x;
+        const float face_y = G->org[1] + (d.y > 0.0f ? G->h : 0.0f) - o.y;
+        const float face_z = G->org[2] + (d.z > 0.0f ? G->h : 0.0f) - o.z;
 
         for (;;) {
             // ---- walkers whose cell is used up: stop, or cross faces (the nearest; one per hop when two are due at
@@ -1073,9 +1100,9 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
                     cy += my ? step_y : 0;
                     cz += mz ? step_z : 0;
                     const int cm = mx ? cx : my ? cy : cz;
-                    const uint32_t dim = mx ? G.dims[0] : my ? G.dims[1] : G.dims[2];
+                    const uint32_t dim = mx ? G->dims[0] : my ? G->dims[1] : G->dims[2];
                     if ((uint32_t)cm >= dim) { walking = false; break; }
-                    const float t_new = fma_((float)cm, G.h, mx ? face_x : my ? face_y : face_z) * (mx ? ix : my ? iy : iz);
+                    const float t_new = fma_((float)cm, G->h, mx ? face_x : my ? face_y : face_z) * (mx ? ix : my ? iy : iz);
                     tx = mx ? t_new : tx;
                     ty = my ? t_new : ty;
                     tz = mz ? t_new : tz;
@@ -1093,9 +1120,10 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(c > j);
                 if (c > j) {
                     const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    const uint32_t i = RES ? (uint32_t)lds_items[k0 + j] : G.items[k0 + j];
-                    X.queue[at] = RES ? ((lane << 16) | i) : i;
-                    if (!RES) { X.queue[kQueueSlots + at] = lane; }
+                    const uint32_t i = RES ? (uint32_t)lds_items[k0 + j] : G->items[k0 + j];
+                    const uint32_t who = (lane << 6) | (uint32_t)q;      // walker lane (the ray is in its registers), ray slot
+                    X.queue[at] = RES ? ((who << 16) | i) : i;
+                    if (!RES) { X.queue[kQueueSlots + at] = who; }
                 }
                 queued += (uint32_t)__builtin_popcountll(m);
             }
@@ -1106,19 +1134,20 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
             while (queued >= 64u || (!any && queued > 0u)) {
                 wave_lds_sync();
                 const uint32_t take = min(queued, 64u), base = queued - take;
-                uint32_t owner = lane, i = 0;
+                uint32_t who = lane << 6, i = 0;
                 if (lane < take) {
                     const uint32_t pr = X.queue[base + lane];
-                    if (RES) { owner = pr >> 16; i = pr & 0xFFFFu; }
-                    else     { owner = X.queue[kQueueSlots + base + lane]; i = pr; }
+                    if (RES) { who = pr >> 16; i = pr & 0xFFFFu; }
+                    else     { who = X.queue[kQueueSlots + base + lane]; i = pr; }
                 }
-                const f3 po = mk3(__shfl(o.x, (int)owner, 64), __shfl(o.y, (int)owner, 64), __shfl(o.z, (int)owner, 64));
-                const f3 pd = mk3(__shfl(d.x, (int)owner, 64), __shfl(d.y, (int)owner, 64), __shfl(d.z, (int)owner, 64));
-                const float pa = __shfl(a, (int)owner, 64);
+                const int owner = (int)(who >> 6);
+                const f3 po = mk3(__shfl(o.x, owner, 64), __shfl(o.y, owner, 64), __shfl(o.z, owner, 64));
+                const f3 pd = mk3(__shfl(d.x, owner, 64), __shfl(d.y, owner, 64), __shfl(d.z, owner, 64));
+                const float pa = __shfl(a, owner, 64);
                 if (lane < take) {
                     unsigned long long key;
                     test(i, po, pd, pa, key);
-                    if (key != ~0ull) { atomicMin(&X.key[owner >> logL], key); }
+                    if (key != ~0ull) { atomicMin(&X.key[who & 63u], key); }
                 }
                 queued = base;
                 wave_lds_sync();
@@ -1128,7 +1157,7 @@ LUMA_DEV void wave_grid_walk(const GridArgs& G, const uint16_t* __restrict__ lds
 
         // ---- back to the rays' own lanes ----
         if (walk) {
-            const unsigned long long found = X.key[logL ? rank : lane];
+            const unsigned long long found = X.key[lane];
             own = found < own ? found : own;
         }
     }
@@ -1198,14 +1227,15 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
             idx = -1;
             t = FLT_MAX;
             if (want) {                                          // direction grid: no walk, one lane per ray
-                idx = RES == 2 ? scan_view<true>(A.grid, rec_gen, o, d, t, ntests) : scan_view<false>(A.grid, rec_cam, o, d, t, ntests);
+                const auto G = kernarg_grid();
+                idx = RES == 2 ? scan_view<true>(G, rec_gen, o, d, t, ntests) : scan_view<false>(G, rec_cam, o, d, t, ntests);
             }
         } else {
             wave_scan<true>(rec_cam, n_pad, lane_of_wave(), want, o, d, idx, t);
         }
     };
     auto scan_gen = [&](bool want, f3 o, f3 d, int& idx, float& t) {
-        if (GRID) { wave_grid_walk<(RES != 0)>(A.grid, grid_cells, grid_items, rec_gen, xch, lane_of_wave(), want, o, d, idx, t, ntests); }
+        if (GRID) { wave_grid_walk<(RES != 0)>(kernarg_grid(), grid_cells, grid_items, rec_gen, xch, lane_of_wave(), want, o, d, idx, t, ntests); }
         else      { wave_scan<false>(rec_gen, n_pad, lane_of_wave(), want, o, d, idx, t); }
     };
 
