@@ -160,18 +160,22 @@ LUMA_DEV uint32_t global_row(const RenderArgs& A, uint32_t yl)
 }
 
 // One entry of Camera::recompute_rays, Camera.cpp:193-213, in registers.
-LUMA_DEV f3 camera_ray(const RenderArgs& A, uint32_t x, uint32_t y)
+template <typename ArgsPtr>
+LUMA_DEV f3 camera_ray(ArgsPtr A, uint32_t x, uint32_t y)
 {
-    float cx = (float)x / (float)A.width;
-    float cy = (float)y / (float)A.height;
+    float proj_inv[16], view_inv[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { proj_inv[i] = A->proj_inv[i]; view_inv[i] = A->view_inv[i]; }
+    float cx = (float)x / (float)A->width;
+    float cy = (float)y / (float)A->height;
     cx = cx * 2.f - 1.f;
     cy = cy * 2.f - 1.f;
     float target[4];
-    apply4(A.proj_inv, cx, cy, 1.f, 1.f, target);
+    apply4(proj_inv, cx, cy, 1.f, 1.f, target);
     const float scalar = 1.0f / target[3];
     f3 n = normalize3(scale3(mk3(target[0], target[1], target[2]), scalar));
     float ray[4];
-    apply4(A.view_inv, n.x, n.y, n.z, 0.f, ray);
+    apply4(view_inv, n.x, n.y, n.z, 0.f, ray);
     return mk3(ray[0], ray[1], ray[2]);
 }
 
@@ -415,9 +419,18 @@ LUMA_DEV KernargGridPtr kernarg_grid()
     asm volatile("" : "+s"(p));
     return (KernargGridPtr)(p + offsetof(RenderArgs, grid));
 }
+typedef const __attribute__((address_space(4))) RenderArgs* KernargArgsPtr;
+LUMA_DEV KernargArgsPtr kernarg_args()
+{
+    auto p = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return (KernargArgsPtr)p;
+}
 #else
 typedef const GridArgs* KernargGridPtr;
 LUMA_DEV KernargGridPtr kernarg_grid() { return nullptr; }
+typedef const RenderArgs* KernargArgsPtr;
+LUMA_DEV KernargArgsPtr kernarg_args() { return nullptr; }
 #endif
 
 // Closest hit of a ray FROM camera.pos through the direction grid (FLAG_GRID; luma_grid.h
@@ -619,7 +632,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     if (SPLIT > 1 && k == 0) { claim[wv * 64 + lane] = 0u; }
     f3 dir0 = mk3(0.f, 0.f, -1.f);
     float blur = 0.f, gainf = 1.f;
-    if (live) { dir0 = camera_ray(A, x, y); }                    // camera.rays[index], :413
+    if (live) { dir0 = camera_ray(&A, x, y); }                    // camera.rays[index], :413
     if (live && k == 0) {
         float t0;
         const int h0 = closest_cam(campos, dir0, t0);
@@ -913,10 +926,11 @@ LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t
 // side: the lanes without such a ray idle through the whole walk, the lanes with one wait for the
 // longest walk of the wave, and inside a hop the lanes whose cell is empty wait for the fullest cell.
 // Here every lane of the wave takes part, in two roles:
-//  * WALKERS.  The W rays that need a walk are numbered and each is given L = 8, 4, 2 or 1 ADJACENT lanes
-//    (the largest power of two with W * L <= 64; origin / direction / range go through LDS), lane s of the
-//    L walking the s-th L-th of the ray's parameter range inside the grid (a 3D-DDA entered at the start of
-//    the segment).  A walker does not test the spheres of its cell: it pushes (walker lane, sphere) pairs
+//  * WALKERS.  Each of the W rays that need a walk gets one lane, and the 64 - W lanes left over are shared out
+//    in proportion to the cells a ray may cross (its length inside the grid in cells, summed over the axes):
+//    a ray owns ADJACENT lanes (a lane finds its ray through a byte map in LDS and a ballot, and reads origin,
+//    direction and range from the owner's registers with ds_bpermute), lane s of its L walking the s-th L-th of
+//    the ray's parameter range inside the grid (a 3D-DDA entered at the start of the segment).  A walker does not test the spheres of its cell: it pushes (walker lane, sphere) pairs
 //    onto a queue of the wave in LDS, at most kPushPerRound per round.
 //  * TESTERS.  Whenever the queue holds a wave's worth of pairs (or no walker is left) all 64 lanes take one
 //    pair each, fetch the pair's ray from its walker's registers (ds_bpermute), run the reference's test
@@ -1012,7 +1026,9 @@ LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, 
         float total = est;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) { total += __shfl_xor(total, off, 64); }
-        // floor of a little less than the exact share: the shares never add up to more than the lanes left over
+        // floor of a little less than the exact share: the shares never add up to more than the lanes left over.
+        // (Measured against it: equal shares, or a blend of the two, lose 3-12 % on every scene size from 1024 to
+        // 65536 spheres; no more than 4 / 8 / 16 lanes per ray lose 1-8 %.)
         const uint32_t cnt = walk ? 1u + (uint32_t)(est * ((float)(64u - W) * 0.999f / total)) : 0u;
         uint32_t start = cnt;                                    // inclusive prefix sum, then exclusive
 #pragma unroll
@@ -1065,10 +1081,18 @@ LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, 
         int cx = 0, cy = 0, cz = 0;
         float tx = FLT_MAX, ty = FLT_MAX, tz = FLT_MAX, ix = 0.f, iy = 0.f, iz = 0.f;
         uint32_t k0 = 0, k1 = 0;
+        // what the rounds below read of the grid arguments, pinned in vector registers for the length of the walk:
+        // left to the register allocator they are re-read from the kernel-argument segment inside the round loop
+        // (a scalar load and its wait per use)
+        float cell_h = G->h;
+        const uint32_t* tab_cells = RES ? nullptr : G->cell_start;
+        const uint32_t* tab_items = RES ? nullptr : G->items;
+        asm volatile("" : "+v"(cell_h));
+        if (!RES) { asm volatile("" : "+v"(tab_cells), "+v"(tab_items)); }
         auto lookup = [&]() {
             const uint32_t id = ((uint32_t)cz * G->dims[1] + (uint32_t)cy) * G->dims[0] + (uint32_t)cx;
             if (RES || lds_cells) { k0 = lds_cells[id]; k1 = lds_cells[id + 1]; }
-            else                  { k0 = G->cell_start[id]; k1 = G->cell_start[id + 1]; }
+            else                  { k0 = tab_cells[id]; k1 = tab_cells[id + 1]; }
         };
         if (walking) {
             enter(o.x, d.x, G->org[0], G->dims[0], cx, tx, ix);
@@ -1102,7 +1126,7 @@ LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, 
                     const int cm = mx ? cx : my ? cy : cz;
                     const uint32_t dim = mx ? G->dims[0] : my ? G->dims[1] : G->dims[2];
                     if ((uint32_t)cm >= dim) { walking = false; break; }
-                    const float t_new = fma_((float)cm, G->h, mx ? face_x : my ? face_y : face_z) * (mx ? ix : my ? iy : iz);
+                    const float t_new = fma_((float)cm, cell_h, mx ? face_x : my ? face_y : face_z) * (mx ? ix : my ? iy : iz);
                     tx = mx ? t_new : tx;
                     ty = my ? t_new : ty;
                     tz = mz ? t_new : tz;
@@ -1120,7 +1144,7 @@ LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, 
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(c > j);
                 if (c > j) {
                     const uint32_t at = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    const uint32_t i = RES ? (uint32_t)lds_items[k0 + j] : G->items[k0 + j];
+                    const uint32_t i = RES ? (uint32_t)lds_items[k0 + j] : tab_items[k0 + j];
                     const uint32_t who = (lane << 6) | (uint32_t)q;      // walker lane (the ray is in its registers), ray slot
                     X.queue[at] = RES ? ((who << 16) | i) : i;
                     if (!RES) { X.queue[kQueueSlots + at] = who; }
@@ -1235,7 +1259,9 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         }
     };
     auto scan_gen = [&](bool want, f3 o, f3 d, int& idx, float& t) {
-        if (GRID) { wave_grid_walk<(RES != 0)>(kernarg_grid(), grid_cells, grid_items, rec_gen, xch, lane_of_wave(), want, o, d, idx, t, ntests); }
+        if (GRID) {
+            wave_grid_walk<(RES != 0)>(kernarg_grid(), grid_cells, grid_items, rec_gen, xch, lane_of_wave(), want, o, d, idx, t, ntests);
+        }
         else      { wave_scan<false>(rec_gen, n_pad, lane_of_wave(), want, o, d, idx, t); }
     };
 
@@ -1266,7 +1292,10 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     const uint32_t pixel = y * A.width + x;                      // global index (:399); unused when !live
     const uint32_t local = yl * A.width + x;
 
-    const f3 dir0 = camera_ray(A, live ? x : 0u, live ? y : 0u); // camera.rays[index], :413
+    // (GRID: the two matrices come from the kernel-argument segment here, once per tile, instead of living in
+    //  SGPRs or spill lanes across the walks)
+    const f3 dir0 = GRID ? camera_ray(kernarg_args(), live ? x : 0u, live ? y : 0u)
+                         : camera_ray(&A, live ? x : 0u, live ? y : 0u);         // camera.rays[index], :413
 
     // DOF pre-pass, :416-432
     int h0;
@@ -1434,7 +1463,7 @@ __global__ void generate_rays_kernel(const RenderArgs A, float* __restrict__ ray
     const uint32_t yl = blockIdx.y;
     const uint32_t y = global_row(A, yl);
     if (x >= A.width || yl >= A.rows) { return; }
-    const f3 d = camera_ray(A, x, y);
+    const f3 d = camera_ray(&A, x, y);
     float* o = rays + 3 * ((size_t)yl * A.width + x);
     o[0] = d.x; o[1] = d.y; o[2] = d.z;
 }
