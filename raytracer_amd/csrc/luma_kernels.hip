@@ -632,7 +632,12 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     if (SPLIT > 1 && k == 0) { claim[wv * 64 + lane] = 0u; }
     f3 dir0 = mk3(0.f, 0.f, -1.f);
     float blur = 0.f, gainf = 1.f;
-    if (live) { dir0 = camera_ray(&A, x, y); }                    // camera.rays[index], :413
+    // The camera's matrices, and further down what only the epilogue needs, are read from the kernel-argument
+    // segment where they are used (kernarg_args) instead of through `A`: as members of the by-value struct they
+    // are all loaded at kernel entry, and the 92 SGPRs that took cost a wave per SIMD (config #3: 74 SGPRs, eight
+    // waves, 1.822 -> 1.800 ms; bands of 2 / 8: 1.003 -> 0.972, 0.290 -> 0.281, profiles/r02/ab_lazy_args.txt).
+    const auto KA = kernarg_args();                              // (taken in uniform control flow)
+    if (live) { dir0 = camera_ray(KA, x, y); }                    // camera.rays[index], :413
     if (live && k == 0) {
         float t0;
         const int h0 = closest_cam(campos, dir0, t0);
@@ -763,6 +768,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
 
     if (SPLIT > 1) { __syncthreads(); }                          // parked frames are visible to the workgroup
 
+    const auto E = kernarg_args();                               // what only the epilogue needs, read here
     if (live && k == 0) {
         if (SPLIT > 1) {
             // the other lanes' frames, added in frame order (:457-458); eight frames' loads are
@@ -783,20 +789,22 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
                 acc_r += park[0]; acc_g += park[npix]; acc_b += park[2 * npix];
             }
         }
-        A.acc[0][local] = acc_r; A.acc[1][local] = acc_g; A.acc[2][local] = acc_b;
+        E->acc[0][local] = acc_r; E->acc[1][local] = acc_g; E->acc[2][local] = acc_b;
 
-        const float inv = 1.0f / A.frame_count_last;             // :460
+        const float inv = 1.0f / E->frame_count_last;            // :460
         int r = (int)((acc_r * inv) * 255.0f);                   // ::RGB, :44-55
         int g = (int)((acc_g * inv) * 255.0f);
         int b = (int)((acc_b * inv) * 255.0f);
-        if (A.flags & FLAG_CLAMP_PACK) {
+        const uint32_t flags = E->flags;
+        if (flags & FLAG_CLAMP_PACK) {
             r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
         }
-        A.target[local] = pack_pixel(r, g, b, A.flags);          // :461
+        E->target[local] = pack_pixel(r, g, b, flags);           // :461
     }
 
-    wave_add_u64(A.counters, nrays);
-    if (GRID) { wave_add_u64(A.counters + 1, ntests); wave_add_u64(A.counters + 2, nrays); }   // tests, and rays of grid launches
+    unsigned long long* const counters = E->counters;
+    wave_add_u64(counters, nrays);
+    if (GRID) { wave_add_u64(counters + 1, ntests); wave_add_u64(counters + 2, nrays); }   // tests, and rays of grid launches
 }
 
 // ---------------------------------------------------------------------------------
