@@ -1300,10 +1300,10 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     const uint32_t pixel = y * A.width + x;                      // global index (:399); unused when !live
     const uint32_t local = yl * A.width + x;
 
-    // (GRID: the two matrices come from the kernel-argument segment here, once per tile, instead of living in
-    //  SGPRs or spill lanes across the walks)
-    const f3 dir0 = GRID ? camera_ray(kernarg_args(), live ? x : 0u, live ? y : 0u)
-                         : camera_ray(&A, live ? x : 0u, live ? y : 0u);         // camera.rays[index], :413
+    // (the two matrices come from the kernel-argument segment here, once per tile, instead of living in SGPRs or
+    //  spill lanes across the scans and walks; so do the accumulator and target pointers at the end of the tile)
+    const auto KA = kernarg_args();
+    const f3 dir0 = camera_ray(KA, live ? x : 0u, live ? y : 0u); // camera.rays[index], :413
 
     // DOF pre-pass, :416-432
     int h0;
@@ -1318,7 +1318,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     const float gainf = (A.show_depth && (focus < .5f)) ? 1.2f : 1.0f;   // :448-452
 
     float acc_r = 0.f, acc_g = 0.f, acc_b = 0.f;
-    if (live) { acc_r = A.acc[0][local]; acc_g = A.acc[1][local]; acc_b = A.acc[2][local]; }
+    if (live) { acc_r = KA->acc[0][local]; acc_g = KA->acc[1][local]; acc_b = KA->acc[2][local]; }
 
     uint32_t s = 0, bounce = 0;
     f3 direct = mk3(0.f, 0.f, 0.f);
@@ -1431,16 +1431,18 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         }
     }
 
+    const auto E = kernarg_args();
     if (live) {
-        A.acc[0][local] = acc_r; A.acc[1][local] = acc_g; A.acc[2][local] = acc_b;
-        const float inv = 1.0f / A.frame_count_last;             // :460
+        E->acc[0][local] = acc_r; E->acc[1][local] = acc_g; E->acc[2][local] = acc_b;
+        const float inv = 1.0f / E->frame_count_last;            // :460
         int r = (int)((acc_r * inv) * 255.0f);                   // ::RGB, :44-55
         int g = (int)((acc_g * inv) * 255.0f);
         int b = (int)((acc_b * inv) * 255.0f);
-        if (A.flags & FLAG_CLAMP_PACK) {
+        const uint32_t flags = E->flags;
+        if (flags & FLAG_CLAMP_PACK) {
             r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
         }
-        A.target[local] = pack_pixel(r, g, b, A.flags);          // :461
+        E->target[local] = pack_pixel(r, g, b, flags);           // :461
     }
   }  // next tile
 
