@@ -351,12 +351,14 @@ def test_grid_equals_linear_scan_on_a_config5_band(abi):
     assert frames["grid"][2].sphere_tests * 100 < frames["linear"][2].sphere_tests
 
 
-@pytest.mark.parametrize("kind", ["cluster_and_outliers", "line", "coincident", "shells", "flat"])
-def test_grid_on_awkward_distributions(abi, oracle, kind):
-    """Scenes a uniform grid handles badly (everything in one cell, a line of cells, hundreds of
-    identical or concentric spheres, a plane): still the linear scan's frame."""
+@pytest.mark.parametrize("kind,n", [("cluster_and_outliers", 600), ("line", 600), ("coincident", 600), ("shells", 600), ("flat", 600),
+                                    # the wave-cooperative walk's other tiers: tables in LDS / everything in global memory
+                                    ("cluster_and_outliers", 6000), ("coincident", 6000), ("flat", 7000),
+                                    ("cluster_and_outliers", 20000), ("shells", 20000), ("line", 20000)])
+def test_grid_on_awkward_distributions(abi, oracle, kind, n):
+    """Scenes a uniform grid handles badly (everything in one cell, a line of cells, hundreds or thousands
+    of identical or concentric spheres, a plane): still the linear scan's frame."""
     rng = np.random.default_rng({"cluster_and_outliers": 1, "line": 2, "coincident": 3, "shells": 4, "flat": 5}[kind])
-    n = 600
     pos = np.zeros((n, 3), np.float32)
     rad = np.full(n, 0.3, np.float32)
     if kind == "cluster_and_outliers":
@@ -367,7 +369,7 @@ def test_grid_on_awkward_distributions(abi, oracle, kind):
         pos[:, 0] = 0.01 * np.arange(n)
     elif kind == "coincident":
         pos[:] = [0.5, 0.2, -9]
-        pos[300:] = [-1.5, 0.1, -7]
+        pos[n // 2:] = [-1.5, 0.1, -7]
         rad[:] = 1.0
     elif kind == "shells":
         pos[:] = [0, 0, -15]
@@ -382,9 +384,9 @@ def test_grid_on_awkward_distributions(abi, oracle, kind):
         o.pos[:] = [float(v) for v in pos[i]]; o.radius = float(rad[i]); o.diffuse[:] = d
         o.albedo, o.metallic, o.roughness = 1.0, [.001, .1, .4][i % 3], 0.3
     assert bytes(a_scene) == bytes(o_scene)
-    W, H = 80, 45
+    W, H = (80, 45) if n <= 1000 else (48, 27)
     for flags in (1, 0, 2):
-        kw = dict(spp=2, bounces=4, paths=1, samples=1, mode=1, seed=SEED)
+        kw = dict(spp=2 if n <= 1000 else 1, bounces=4 if n <= 1000 else 3, paths=1, samples=1, mode=1, seed=SEED)
         got, acc, st = hip_render(abi, a_scene, abi.default_camera(W, H), W, H, flags=flags | abi.FLAG_GRID, **kw)
         want, wacc, _ = oracle.render(o_scene, oracle.camera(W, H), oracle.make_params(W, H, flags=flags, **kw))
         assert_frames_equal(got, want, f"grid, {kind}, flags={flags}")
