@@ -954,14 +954,14 @@ LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t
 constexpr uint32_t kPushPerRound = 2u;
 constexpr uint32_t kHopsPerRound = 1u;
 constexpr uint32_t kQueueSlots = 64u + 64u * kPushPerRound;    // fewer than 64 pairs stay behind a drain
-// per wave, in float4 slots: 32 rays x 2, then 64 keys x 8 B, then the queue
-constexpr uint32_t kCoopSlotsPerWave = 64u + 32u + kQueueSlots / 4u;
+// per wave, in float4 slots: the 64-byte lane map, then 64 keys x 8 B, then the queue
+constexpr uint32_t kCoopSlotsPerWave = 4u + 32u + kQueueSlots / 4u;
 LUMA_DEV uint32_t lane_of_wave() { return threadIdx.x & 63u; }
 
 struct CoopLds {
-    float4* ray;                    // per wave: 32 x 2 float4: (origin.xyz, t0), (dir.xyz, t1)
-    unsigned long long* key;        // per wave: 64 x ((t bits << 32) | index), the best hit of ray slot q
-    uint32_t* queue;                // per wave: kQueueSlots x ((walker lane << 16 | 0) ... see pack below)
+    uint8_t* map;                   // per wave: 64 bytes, the first lane of each ray's run of lanes marked with its owner
+    unsigned long long* key;        // per wave: 64 x ((t bits << 32) | index), the best hit of ray slot q (= the owner's lane)
+    uint32_t* queue;                // per wave: kQueueSlots x (walker lane << 22 | ray slot << 16 | sphere); !RES: two planes
 };
 
 LUMA_DEV void wave_lds_sync()
@@ -1047,7 +1047,7 @@ LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, 
         start -= cnt;
         // lane j finds its ray: owners mark the first lane of their run in a byte map, the marks' ballot gives every
         // lane the start of its run, and the ray comes from the owner's registers (ds_bpermute)
-        uint8_t* const map = reinterpret_cast<uint8_t*>(X.ray);
+        uint8_t* const map = X.map;
         map[lane] = 0;
         wave_lds_sync();
         if (walk) { map[start] = (uint8_t)(0x80u | lane); }
@@ -1237,9 +1237,9 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
             next += (A.grid.n_items + 7u) / 8u;
         }
         float4* mine = next + (threadIdx.x >> 6) * (RES ? kCoopSlotsPerWave : kCoopSlotsPerWave + kQueueSlots / 4u);
-        xch.ray = mine;
-        xch.key = reinterpret_cast<unsigned long long*>(mine + 64);
-        xch.queue = reinterpret_cast<uint32_t*>(mine + 96);     // !RES: a second plane of kQueueSlots words holds the walker lanes
+        xch.map = reinterpret_cast<uint8_t*>(mine);
+        xch.key = reinterpret_cast<unsigned long long*>(mine + 4);
+        xch.queue = reinterpret_cast<uint32_t*>(mine + 36);     // !RES: a second plane of kQueueSlots words holds the walker lanes
         __syncthreads();
     } else {
         const float qnan = __builtin_nanf("");
