@@ -952,7 +952,6 @@ LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t
 // superset of what the lane-per-ray walk needs and the result is the linear scan's.
 // ---------------------------------------------------------------------------------
 constexpr uint32_t kPushPerRound = 2u;
-constexpr uint32_t kHopsPerRound = 1u;
 constexpr uint32_t kQueueSlots = 64u + 64u * kPushPerRound;    // fewer than 64 pairs stay behind a drain
 // per wave, in float4 slots: the 64-byte lane map, then 64 keys x 8 B, then the queue
 constexpr uint32_t kCoopSlotsPerWave = 4u + 32u + kQueueSlots / 4u;
@@ -1118,28 +1117,28 @@ LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, 
         const float face_z = G->org[2] + (d.z > 0.0f ? G->h : 0.0f) - o.z;
 
         for (;;) {
-            // ---- walkers whose cell is used up: stop, or cross faces (the nearest; one per hop when two are due at
-            //      at once) until a cell lists something, at most kHopsPerRound a round.  Branch free: the lanes of
-            //      a wave cross different faces.  (The crossing times only steer the walk and its margins; the
-            //      tests' arithmetic is untouched by how they are rounded.)
+            // ---- walkers whose cell is used up: stop, or cross the nearest face (one per round when two are due at
+            //      once).  Branch free: the lanes of a wave cross different faces.  (The crossing times only steer
+            //      the walk and its margins; the tests' arithmetic is untouched by how they are rounded.  Crossing
+            //      up to four empty cells in one round was slower: every round then pays for the longest skip.)
             if (walking && k0 == k1) {
                 const float best_t = __builtin_bit_cast(float, (uint32_t)(X.key[q] >> 32));
-                for (uint32_t hop = 0; hop < kHopsPerRound; hop++) {
-                    const float t_exit = __builtin_fminf(__builtin_fminf(tx, ty), tz);
-                    if (best_t < t_exit - margin || t_exit > te + margin || --hops_left == 0u) { walking = false; break; }
+                const float t_exit = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+                if (best_t < t_exit - margin || t_exit > te + margin || --hops_left == 0u) {
+                    walking = false;
+                } else {
                     const bool mx = tx <= ty && tx <= tz, my = !mx && ty <= tz, mz = !mx && !my;
                     cx += mx ? step_x : 0;
                     cy += my ? step_y : 0;
                     cz += mz ? step_z : 0;
                     const int cm = mx ? cx : my ? cy : cz;
                     const uint32_t dim = mx ? G->dims[0] : my ? G->dims[1] : G->dims[2];
-                    if ((uint32_t)cm >= dim) { walking = false; break; }
+                    walking = (uint32_t)cm < dim;
                     const float t_new = fma_((float)cm, cell_h, mx ? face_x : my ? face_y : face_z) * (mx ? ix : my ? iy : iz);
                     tx = mx ? t_new : tx;
                     ty = my ? t_new : ty;
                     tz = mz ? t_new : tz;
-                    lookup();
-                    if (k0 != k1) { break; }
+                    if (walking) { lookup(); }
                 }
             }
 
