@@ -1564,7 +1564,10 @@ hipError_t static_scratch_address(void** ptr)
 // ---------------------------------------------------------------------------------
 // Launchers (host).  Shapes are validated by the C-ABI layer before these are called.
 // ---------------------------------------------------------------------------------
+// Pixels per wave: 16x4 tiles in the wave-uniform kernels, 32x2 in the ray-per-lane kernel (whole 1080p frame the
+// same either way; bands of 4 / 8 of it 0.527 -> 0.505, 0.283 -> 0.277 ms; the wave-uniform kernels 1 % slower at 32x2)
 static constexpr int kTileW = 16;
+static constexpr int kLaneTileW = 32;
 
 size_t scene_lds_bytes(uint32_t n_spheres) { return (size_t)n_spheres * 2u * sizeof(float4); }
 
@@ -1580,7 +1583,6 @@ hipError_t launch_prepare_records(const float* cx, const float* cy, const float*
 
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 {
-    constexpr int tile_h = 64 / kTileW;
     const uint32_t rows = args.rows;
     const uint32_t n = args.n_spheres;
     const bool noise = !(args.flags & FLAG_NOISE_OFF), from_hit = (args.flags & FLAG_ORIGIN_FROM_HIT) != 0;
@@ -1631,8 +1633,8 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         lds = scene == SCENE_LDS_ALL ? all_bytes : 0;
         waves = 4;
         split = args.split;
-#define LUMA_K(S, P, G) { { render_kernel<kTileW, 4, S, false, false, P, G>, render_kernel<kTileW, 4, S, false, true, P, G> }, \
-                          { render_kernel<kTileW, 4, S, true, false, P, G>,  render_kernel<kTileW, 4, S, true, true, P, G> } }
+#define LUMA_K(S, P, G) { { render_kernel<kLaneTileW, 4, S, false, false, P, G>, render_kernel<kLaneTileW, 4, S, false, true, P, G> }, \
+                          { render_kernel<kLaneTileW, 4, S, true, false, P, G>,  render_kernel<kLaneTileW, 4, S, true, true, P, G> } }
         static const kernel_t table[3][2][2][2] = {
             { LUMA_K(SCENE_GLOBAL, 1, false), LUMA_K(SCENE_LDS_ALL, 1, false) },
             { LUMA_K(SCENE_GLOBAL, 2, false), LUMA_K(SCENE_LDS_ALL, 2, false) },
@@ -1647,8 +1649,8 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         // rays: instances with the sphere count as a compile-time constant, their scans fully unrolled
         // (config #3: 1.93 -> 1.84 ms, profiles/r02/ab_unrolled_scan.txt)
         if (scene == SCENE_LDS_ALL && !use_grid && !from_hit && n >= 1 && n <= 8) {
-#define LUMA_NS(P, N) { render_kernel<kTileW, 4, SCENE_LDS_ALL, false, false, P, false, N>, \
-                        render_kernel<kTileW, 4, SCENE_LDS_ALL, true, false, P, false, N> }
+#define LUMA_NS(P, N) { render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, false, false, P, false, N>, \
+                        render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, false, P, false, N> }
 #define LUMA_NS8(P) { LUMA_NS(P, 1), LUMA_NS(P, 2), LUMA_NS(P, 3), LUMA_NS(P, 4), LUMA_NS(P, 5), LUMA_NS(P, 6), LUMA_NS(P, 7), LUMA_NS(P, 8) }
             static const kernel_t ns_table[3][8][2] = { LUMA_NS8(1), LUMA_NS8(2), LUMA_NS8(4) };
 #undef LUMA_NS8
@@ -1664,7 +1666,8 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     }
     const int wpk = waves / split;                               // waves that tile pixels (the rest split frames)
     const int wgx = wg_waves_x(wpk), wgy = wpk / wgx;
-    dim3 grid((args.width + wgx * kTileW - 1) / (wgx * kTileW), (rows + wgy * tile_h - 1) / (wgy * tile_h));
+    const int tile_w = sphere_parallel ? kTileW : kLaneTileW, tile_h = 64 / tile_w;
+    dim3 grid((args.width + wgx * tile_w - 1) / (wgx * tile_w), (rows + wgy * tile_h - 1) / (wgy * tile_h));
     if (sphere_parallel) {
         // persistent waves: one resident set of workgroups, tiles handed out by a counter
         int cus = 256;
@@ -1672,7 +1675,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         if (hipGetDevice(&dev) == hipSuccess) { (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); }
         const size_t by_lds = (160u * 1024u) / (lds ? lds : 1);
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(32 / waves, by_lds));
-        const uint32_t n_tiles = ((args.width + kTileW - 1) / kTileW) * ((rows + tile_h - 1) / tile_h);
+        const uint32_t n_tiles = ((args.width + tile_w - 1) / tile_w) * ((rows + tile_h - 1) / tile_h);
         const size_t want = (n_tiles + waves - 1) / waves;
         grid = dim3((unsigned)std::max<size_t>(1, std::min<size_t>(want, per_cu * (size_t)cus)), 1);
     }
