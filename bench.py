@@ -283,7 +283,7 @@ def main():
 
     # frame leg (SURVEY 8d "frame ms", what the reference itself times: one whole render_to,
     # main.cpp:261-276): wall clock of one call that ends with the finished frame in HOST memory.
-    # One GPU: luma_hip_render into a page-locked frame (kernel + D2H).  N ranks: render, gather of
+    # One GPU: luma_hip_render into a page-locked frame (the kernel writes it over PCIe as it goes).  N ranks: render, gather of
     # the bands on rank 0 (not pipelined: the frame is waited for), D2H of the assembled frame.
     n_frame = max(1, min(a.steps, 20))
     if world == 1 and not a.force_dist:
@@ -345,7 +345,7 @@ def main():
             # ms_per_step (and value) time the step with the frame left in HBM, as the bench contract
             # asks; frame_ms is the host-target frame: kernel + (gather) + D2H into page-locked memory
             "frame_ms": frame_ms,
-            "frame_ms_definition": ("wall of luma_hip_render into a page-locked host frame (kernel + D2H)" if world == 1 and not a.force_dist
+            "frame_ms_definition": ("wall of luma_hip_render into a page-locked host frame (written by the kernel over PCIe, no copy after it)" if world == 1 and not a.force_dist
                                     else "wall of render + gather of the bands on rank 0 + D2H of the frame, not pipelined, max over ranks"),
             "msamples_per_s": WIDTH * (HEIGHT // (a.emulate_world or 1)) * SPP * a.steps / dt / 1e6,
             "rays_per_step": rays_per_step,

@@ -78,6 +78,8 @@ struct RenderArgs {
     // outputs (band-local)
     float*    acc[3];           // accumulation planes r, g, b
     uint32_t* target;           // 0x00RRGGBB
+    uint32_t* target_mirror;    // the same pixels a second time, or null: page-locked host memory written by the kernel itself,
+    uint32_t  mirror_is_frame;  // a band laid out like `target` (0) or the whole width x height frame (1: indexed by frame pixel)
     // frame splitting (ray-per-lane kernel): lanes per pixel (1, 2 or 4) and the planes where
     // lanes 1.. park their frames: spp x 3 x band pixels floats (one slot per frame)
     uint32_t  split;

@@ -799,7 +799,10 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
         if (flags & FLAG_CLAMP_PACK) {
             r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
         }
-        E->target[local] = pack_pixel(r, g, b, flags);           // :461
+        const uint32_t px = pack_pixel(r, g, b, flags);
+        E->target[local] = px;                                   // :461
+        uint32_t* const mirror = E->target_mirror;
+        if (mirror) { mirror[E->mirror_is_frame ? pixel : local] = px; }
     }
 
     unsigned long long* const counters = E->counters;
@@ -1441,7 +1444,10 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         if (flags & FLAG_CLAMP_PACK) {
             r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
         }
-        E->target[local] = pack_pixel(r, g, b, flags);           // :461
+        const uint32_t px = pack_pixel(r, g, b, flags);
+        E->target[local] = px;                                   // :461
+        uint32_t* const mirror = E->target_mirror;
+        if (mirror) { mirror[E->mirror_is_frame ? pixel : local] = px; }
     }
   }  // next tile
 

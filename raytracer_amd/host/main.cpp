@@ -78,8 +78,8 @@ int main(int argc, char** argv)
                                 luma::_options.pitch, luma::_options.yaw);
     }
     const std::size_t pixels = static_cast<std::size_t>(luma::_options.width) * luma::_options.height;
-    // main.cpp:259 has `new std::uint32_t[width * height]`; a page-locked frame lets the devices
-    // write it by DMA (0.15 ms instead of 0.5-1.1 ms per 1080p frame, tools/hostpath_timing.py)
+    // main.cpp:259 has `new std::uint32_t[width * height]`; a page-locked frame is written by the render
+    // kernels themselves while they run (no copy after them; pageable memory costs 0.5-1.1 ms per 1080p frame)
     struct HostFree { void operator()(std::uint32_t* p) const { luma_hip_host_free(p); } };
     void* raw = nullptr;
     if (luma_hip_host_alloc(&raw, pixels * sizeof(std::uint32_t)) != LUMA_OK) {

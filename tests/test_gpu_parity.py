@@ -733,6 +733,53 @@ def test_page_locked_host_frame(abi):
     assert e.value.code == abi.E_ARG
 
 
+@pytest.mark.parametrize("n,flags", [(5, 0), (5, 16), (700, 0), (3000, 32)])
+def test_kernel_written_host_target(abi, n, flags):
+    """luma_hip_render into a page-locked target: the kernel writes the host band itself (no copy after it).
+    The band equals the one a pageable target gets, the context's own framebuffer holds it too, and a band
+    that is not the whole frame lands in a page-locked buffer of just its size -- for the ray-per-lane, the
+    sphere-parallel and the grid kernels."""
+    W, H = 192, 108
+    scene = abi.default_scene() if n == 5 else abi.synthetic_scene(n)
+    p = abi.make_params(W, H, spp=3, bounces=5, paths=1, samples=1, mode=1, flags=flags, seed=SEED)
+    for rows in ((0, H), (27, 81)):
+        with abi.Context(0) as a, abi.Context(0) as b, abi.HostFrame(rows[1] - rows[0], W) as hf:
+            for ctx in (a, b):
+                ctx.set_scene(scene); ctx.set_camera(abi.default_camera(W, H)); ctx.set_frame(W, H, *rows)
+            want, _ = a.render(p)                            # pageable numpy target: hipMemcpy after the kernel
+            hf.array[:] = 0xDEADBEEF
+            got, _ = b.render(p, out=hf.array)
+            assert_frames_equal(got.copy(), want, f"kernel-written host target, rows {rows}")
+            assert_frames_equal(b.read_target(), want, "the context's own framebuffer")
+            got2, _ = b.render(p, out=hf.array)              # accumulates on: frames 4..6
+            want2, _ = a.render(p)
+            assert_frames_equal(got2.copy(), want2, "second call")
+
+
+def test_kernel_written_host_frame(abi):
+    """luma_hip_render_frame and luma_hip_group_render into a page-locked FRAME: every context's kernel writes its
+    own rows of it (contiguous bands and interleaved stripes); same frame as through a pageable one."""
+    W, H = 160, 120
+    p = abi.make_params(W, H, spp=2, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    want, _, _ = hip_render(abi, abi.default_scene(), abi.default_camera(W, H), W, H, spp=2, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    with abi.HostFrame(H, W) as hf:
+        for striped in (False, True):
+            hf.array[:] = 0
+            for r in range(4):
+                with abi.Context(0) as ctx:
+                    ctx.set_scene(abi.default_scene()); ctx.set_camera(abi.default_camera(W, H))
+                    if striped: ctx.set_frame_striped(W, H, 15, r, 4)
+                    else: ctx.set_frame(W, H, r * 30, (r + 1) * 30)
+                    ctx.render_frame(p, hf.array)
+            assert_frames_equal(hf.array.copy(), want, f"render_frame, striped={striped}")
+        for ids in ([0], [0, 0, 0], [0] * 8):
+            hf.array[:] = 0
+            with abi.Group(ids) as g:
+                g.set_scene(abi.default_scene()); g.set_camera(abi.default_camera(W, H)); g.set_frame(W, H)
+                g.render(p, out=hf.array)
+            assert_frames_equal(hf.array.copy(), want, f"group of {len(ids)}")
+
+
 def test_group_errors(abi):
     with pytest.raises(abi.LumaError) as e:
         abi.Group([])
