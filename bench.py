@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-frame-leg", action="store_true",
+                    help="skip the host-delivery leg (frame_ms = 0): profiler runs then see only the device-target launches the roofline is quoted on")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="config3")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="profiling aid: render only one band of this many bands on one GPU")
@@ -286,7 +288,9 @@ def main():
     # One GPU: luma_hip_render into a page-locked frame (the kernel writes it over PCIe as it goes).  N ranks: render, gather of
     # the bands on rank 0 (not pipelined: the frame is waited for), D2H of the assembled frame.
     n_frame = max(1, min(a.steps, 20))
-    if world == 1 and not a.force_dist:
+    if a.no_frame_leg:
+        frame_ms = 0.0
+    elif world == 1 and not a.force_dist:
         with abi.HostFrame(y1 - y0, WIDTH) as hf:
             ctx.render(params, want_stats=False, out=hf.array)    # first touch of the frame
             t1 = time.perf_counter()

@@ -13,7 +13,7 @@ for lib in $OLD raytracer_amd/libluma_hip.so; do
   timeout -k 10 300 python3 tools/grid_coop_sweep.py > "$OUT/grid_coop_sweep.$tag.txt" 2>&1 || { echo "sweep $tag failed"; exit 1; }
 done
 unset LUMA_HIP_LIB
-timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --no-cpu-baseline --workload config5 --emulate-world 8 --grid --steps 5 --warmup 1 > "$OUT/kt.json" 2> "$OUT/kt.err" || { echo "kernel-trace failed"; tail -3 "$OUT/kt.err"; exit 1; }
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -- python3 bench.py --no-cpu-baseline --no-frame-leg --workload config5 --emulate-world 8 --grid --steps 5 --warmup 1 > "$OUT/kt.json" 2> "$OUT/kt.err" || { echo "kernel-trace failed"; tail -3 "$OUT/kt.err"; exit 1; }
 f=$(find "$OUT/kt" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/config5_band_of_8_grid_kernel_stats.csv"
 BENCH_ARGS="--workload config5 --emulate-world 8 --grid" bash tools/pmc_ab.sh "$OUT/pmc" $OLD raytracer_amd/libluma_hip.so > "$OUT/config5_band8_grid_pmc_summary.txt" 2>&1 || { tail -5 "$OUT/config5_band8_grid_pmc_summary.txt"; exit 1; }
 echo done
