@@ -159,6 +159,18 @@ LUMA_DEV uint32_t global_row(const RenderArgs& A, uint32_t yl)
     return A.row_begin + (yl / A.stripe) * A.pitch + (yl % A.stripe);
 }
 
+// Band-local pixel index -> index in the whole frame.  Recomputed where it is needed (once per pixel and launch, in
+// the epilogue) from the one index that is live there: a register held across the render loop for it costs the
+// ray-per-lane kernel its eighth wave per SIMD (65 VGPRs).
+template <typename ArgsPtr>
+LUMA_DEV uint32_t frame_pixel(ArgsPtr A, uint32_t local)
+{
+    const uint32_t w = A->width, stripe = A->stripe;
+    const uint32_t yl = local / w, x = local - yl * w;
+    const uint32_t y = A->row_begin + (yl / stripe) * A->pitch + (yl % stripe);
+    return y * w + x;
+}
+
 // One entry of Camera::recompute_rays, Camera.cpp:193-213, in registers.
 template <typename ArgsPtr>
 LUMA_DEV f3 camera_ray(ArgsPtr A, uint32_t x, uint32_t y)
@@ -802,7 +814,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
         const uint32_t px = pack_pixel(r, g, b, flags);
         E->target[local] = px;                                   // :461
         uint32_t* const mirror = E->target_mirror;
-        if (mirror) { mirror[E->mirror_is_frame ? pixel : local] = px; }
+        if (mirror) { mirror[E->mirror_is_frame ? frame_pixel(E, local) : local] = px; }
     }
 
     unsigned long long* const counters = E->counters;
@@ -1447,7 +1459,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
         const uint32_t px = pack_pixel(r, g, b, flags);
         E->target[local] = px;                                   // :461
         uint32_t* const mirror = E->target_mirror;
-        if (mirror) { mirror[E->mirror_is_frame ? pixel : local] = px; }
+        if (mirror) { mirror[E->mirror_is_frame ? frame_pixel(E, local) : local] = px; }
     }
   }  // next tile
 

@@ -1,0 +1,60 @@
+"""The headline kernel's register budget, checked where the library is built (no GPU needed): the config #3
+instance of the ray-per-lane kernel runs eight waves per SIMD only with at most 64 VGPRs and 80 SGPRs and no
+spills; one more live value in its loop costs a wave per SIMD and ~1.5 % (profiles/r02/
+ab_lazy_args.txt).  Compiles luma_kernels.hip to assembly once (about a minute) and reads the kernels' metadata."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "raytracer_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def kernel_metadata(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not found")
+    out = tmp_path_factory.mktemp("asm") / "luma_kernels.s"
+    flags = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize"]   # raytracer_amd/csrc/Makefile
+    subprocess.check_call([HIPCC] + flags + ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "--offload-arch=gfx950",
+                                             "--cuda-device-only", "-S", "-o", str(out), os.path.join(CSRC, "luma_kernels.hip")],
+                          stderr=subprocess.DEVNULL, timeout=600)
+    text = out.read_text()
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.wavefront_size", text, re.S):
+        meta[m.group(1)] = {k: int(v) for k, v in re.findall(r"\.(\w+_count|private_segment_fixed_size):\s+(\d+)", m.group(2))}
+    return meta
+
+
+def test_makefile_flags_are_the_ones_checked():
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    for flag in ("-O3", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "--offload-arch=$(ARCH)", "ARCH     ?= gfx950"):
+        assert flag in mk, flag
+
+
+def test_config3_kernel_keeps_eight_waves_per_simd(kernel_metadata):
+    # render_kernel<TILE_W=32, WAVES=4, SCENE_LDS_ALL, NOISE, !FROM_HIT, SPLIT=1, !GRID, NS=5>
+    names = [n for n in kernel_metadata if re.search(r"render_kernelILi32ELi4ELi2ELb1ELb0ELi1ELb0ELi5E", n)]
+    assert len(names) == 1, names
+    k = kernel_metadata[names[0]]
+    assert k["vgpr_count"] <= 64, k
+    assert k["sgpr_count"] <= 80, k
+    assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+
+
+def test_kernels_behind_the_no_alloc_entry_point_use_no_private_memory(kernel_metadata):
+    # luma_hip_render_device_noalloc refuses LUMA_FLAG_GRID only: every other render kernel must run without the
+    # scratch memory the HIP runtime would allocate at dispatch (include/luma_hip.h)
+    checked = 0
+    for name, k in kernel_metadata.items():
+        m = re.search(r"render_kernelILi\d+ELi\d+ELi\d+ELb[01]ELb[01]ELi\d+ELb([01])E", name)
+        sp = re.search(r"render_kernel_spILi\d+ELi\d+ELb[01]ELb[01]ELb([01])E", name)
+        grid = (m and m.group(1) == "1") or (sp and sp.group(1) == "1")
+        if (m or sp) and not grid:
+            assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, (name, k)
+            checked += 1
+    assert checked >= 40
