@@ -13,8 +13,8 @@ stats() {   # name, bench args...
   [ -n "$f" ] && cp "$f" "$OUT/${name}_kernel_stats.csv"
   echo "== $name"; head -4 "$OUT/${name}_kernel_stats.csv"
 }
-stats config3 --steps 20 --warmup 3 || exit 1
-for w in 2 4 8; do stats config3_band_of_$w --steps 20 --warmup 3 --emulate-world $w || exit 1; done
+stats config3 --steps 100 --warmup 10 || exit 1
+for w in 2 4 8; do stats config3_band_of_$w --steps 100 --warmup 10 --emulate-world $w || exit 1; done
 stats config2 --workload config2 --steps 50 --warmup 5 || exit 1
 stats config5_band_of_8 --workload config5 --emulate-world 8 --steps 3 --warmup 1 || exit 1
 stats config5_band_of_8_grid --workload config5 --emulate-world 8 --grid --steps 5 --warmup 1 || exit 1
