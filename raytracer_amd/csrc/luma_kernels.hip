@@ -966,7 +966,7 @@ LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t
 // point; pairs pushed beyond that are tested all the same and can only lose.  So the set of tests is a
 // superset of what the lane-per-ray walk needs and the result is the linear scan's.
 // ---------------------------------------------------------------------------------
-constexpr uint32_t kPushPerRound = 2u;
+constexpr uint32_t kPushPerRound = 3u;                         // (1 / 2 / 3 / 4: config #5 band 7.89 / 7.19 / 7.07 / 7.13 ms)
 constexpr uint32_t kQueueSlots = 64u + 64u * kPushPerRound;    // fewer than 64 pairs stay behind a drain
 // per wave, in float4 slots: the 64-byte lane map, then 64 keys x 8 B, then the queue
 constexpr uint32_t kCoopSlotsPerWave = 4u + 32u + kQueueSlots / 4u;

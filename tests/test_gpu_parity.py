@@ -309,7 +309,7 @@ def test_synthetic_scene(abi, oracle, n, W, H, spp, flags, paths):
     # bounce rays (flag 2) and without noise (flag 1), and too large for LDS (tables in global memory) likewise
     (511, 64, 36, 2, 0, False), (512, 64, 36, 2, 0, False), (2500, 80, 45, 3, 3, True), (4500, 64, 36, 2, 2, False),
     (20000, 48, 27, 2, 2, True), (9000, 64, 36, 2, 1, True), (70000, 48, 27, 1, 2, False),
-    # ... and with the grid's tables in LDS but the records in global memory (about 5300 to 11000 spheres)
+    # ... and with the grid's tables in LDS but the records in global memory (about 5100 to 11000 spheres)
     (6000, 64, 36, 2, 2, False), (7000, 48, 27, 2, 1, True), (8000, 64, 36, 1, 0, False), (5200, 48, 27, 1, 0, False),
 ])
 def test_grid_gives_the_linear_scan_frame(abi, oracle, n, W, H, spp, flags, posed):
