@@ -156,8 +156,11 @@ bool tangent_range(double qa, double qm, double r, double& lo, double& hi)
 void build_view_grid(const luma_sphere* spheres, uint32_t n, const float origin[3], HostViewGrid& g)
 {
     g = HostViewGrid{};
-    // bins about the angular size of a typical sphere: ~2 sqrt(n) per face edge, 16 .. 256
-    const uint32_t res = static_cast<uint32_t>(std::min(256.0, std::max(16.0, std::ceil(2.0 * std::sqrt(double(n) + 1.0)))));
+    // bins about half the angular size of a typical sphere: ~4 sqrt(n) per face edge, 16 .. 256.  The kernels pay for
+    // the LONGEST list among a wave's 64 rays, so short lists count for more than the table's size (measured with
+    // 2 / 3 / 4 / 6 sqrt(n): config #5 band 7.05 / 6.52 / 6.29 / 6.65 ms, 1024 spheres 2.99 / 2.65 / 2.50 / 2.45; an edge
+    // beyond 256 thrashes L2 on the offsets: 65536 spheres 10.0 -> 12.2 ms at 512)
+    const uint32_t res = static_cast<uint32_t>(std::min(256.0, std::max(16.0, std::ceil(4.0 * std::sqrt(double(n) + 1.0)))));
     g.res = res;
     const size_t n_bins = size_t(6) * res * res;
 

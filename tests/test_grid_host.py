@@ -131,7 +131,7 @@ def test_view_grid_of_the_benchmark_scenes(abi):
     res, n_items, n_large = check_view_grid(abi, abi.default_scene(), [0, 0, 0], rng)
     assert res == 16                                      # five spheres: the coarsest grid (the ground fills half its bins)
     res, n_items, n_large = check_view_grid(abi, abi.synthetic_scene(4096), [0, 0, 0], rng)
-    assert res == 129 and n_large == 1 and n_items < 40 * 4096
+    assert res == 256 and n_large == 1 and n_items < 60 * 4096   # 4 sqrt(n) bins per face edge, at most 256
 
 
 @pytest.mark.parametrize("seed", range(6))
