@@ -1111,8 +1111,12 @@ LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, 
         const uint32_t* tab_items = RES ? nullptr : G->items;
         asm volatile("" : "+v"(cell_h));
         if (!RES) { asm volatile("" : "+v"(tab_cells), "+v"(tab_items)); }
+        // (the grid's dimensions as three scalars of their own: selected by axis as G->dims[axis] they became a
+        //  load from the kernel-argument segment with a computed address -- a vector memory round trip in every hop)
+        uint32_t dim_x = G->dims[0], dim_y = G->dims[1], dim_z = G->dims[2];
+        asm volatile("" : "+s"(dim_x), "+s"(dim_y), "+s"(dim_z));
         auto lookup = [&]() {
-            const uint32_t id = ((uint32_t)cz * G->dims[1] + (uint32_t)cy) * G->dims[0] + (uint32_t)cx;
+            const uint32_t id = ((uint32_t)cz * dim_y + (uint32_t)cy) * dim_x + (uint32_t)cx;
             if (RES || lds_cells) { k0 = lds_cells[id]; k1 = lds_cells[id + 1]; }
             else                  { k0 = tab_cells[id]; k1 = tab_cells[id + 1]; }
         };
@@ -1123,7 +1127,7 @@ LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, 
             lookup();
         }
         const float margin = 1e-3f * t_cell;
-        uint32_t hops_left = G->dims[0] + G->dims[1] + G->dims[2] + 3u;     // a straight line crosses no more cells
+        uint32_t hops_left = dim_x + dim_y + dim_z + 3u;         // a straight line crosses no more cells
         uint32_t queued = 0;                                     // wave uniform
         const int step_x = d.x > 0.0f ? 1 : -1, step_y = d.y > 0.0f ? 1 : -1, step_z = d.z > 0.0f ? 1 : -1;
         // face crossed after the step to cell c along an axis: t = (org + (c + (d > 0)) * h - o) / d
@@ -1147,7 +1151,7 @@ LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, 
                     cy += my ? step_y : 0;
                     cz += mz ? step_z : 0;
                     const int cm = mx ? cx : my ? cy : cz;
-                    const uint32_t dim = mx ? G->dims[0] : my ? G->dims[1] : G->dims[2];
+                    const uint32_t dim = mx ? dim_x : my ? dim_y : dim_z;
                     walking = (uint32_t)cm < dim;
                     const float t_new = fma_((float)cm, cell_h, mx ? face_x : my ? face_y : face_z) * (mx ? ix : my ? iy : iz);
                     tx = mx ? t_new : tx;
