@@ -1137,28 +1137,29 @@ LUMA_DEV void wave_grid_walk(GridPtr G, const uint16_t* __restrict__ lds_cells, 
 
         for (;;) {
             // ---- walkers whose cell is used up: stop, or cross the nearest face (one per round when two are due at
-            //      once).  Branch free: the lanes of a wave cross different faces.  (The crossing times only steer
+            //      once).  Branch free, the stop tests included: the lanes of a wave cross different faces and stop for
+            //      different reasons.  (The crossing times only steer
             //      the walk and its margins; the tests' arithmetic is untouched by how they are rounded.  Crossing
             //      up to four empty cells in one round was slower: every round then pays for the longest skip.)
-            if (walking && k0 == k1) {
+            {
+                const bool used_up = walking && k0 == k1;
                 const float best_t = __builtin_bit_cast(float, (uint32_t)(X.key[q] >> 32));
                 const float t_exit = __builtin_fminf(__builtin_fminf(tx, ty), tz);
-                if (best_t < t_exit - margin || t_exit > te + margin || --hops_left == 0u) {
-                    walking = false;
-                } else {
-                    const bool mx = tx <= ty && tx <= tz, my = !mx && ty <= tz, mz = !mx && !my;
-                    cx += mx ? step_x : 0;
-                    cy += my ? step_y : 0;
-                    cz += mz ? step_z : 0;
-                    const int cm = mx ? cx : my ? cy : cz;
-                    const uint32_t dim = mx ? dim_x : my ? dim_y : dim_z;
-                    walking = (uint32_t)cm < dim;
-                    const float t_new = fma_((float)cm, cell_h, mx ? face_x : my ? face_y : face_z) * (mx ? ix : my ? iy : iz);
-                    tx = mx ? t_new : tx;
-                    ty = my ? t_new : ty;
-                    tz = mz ? t_new : tz;
-                    if (walking) { lookup(); }
-                }
+                const bool stop = best_t < t_exit - margin || t_exit > te + margin || hops_left <= 1u;
+                hops_left -= used_up ? 1u : 0u;
+                const bool mx = tx <= ty && tx <= tz, my = !mx && ty <= tz, mz = !mx && !my;
+                const int cm = (mx ? cx + step_x : my ? cy + step_y : cz + step_z);
+                const uint32_t dim = mx ? dim_x : my ? dim_y : dim_z;
+                const bool go = used_up && !stop && (uint32_t)cm < dim;      // the walker moves to a cell of the grid
+                walking = walking && (!used_up || go);
+                const float t_new = fma_((float)cm, cell_h, mx ? face_x : my ? face_y : face_z) * (mx ? ix : my ? iy : iz);
+                cx = (go && mx) ? cm : cx;
+                cy = (go && my) ? cm : cy;
+                cz = (go && mz) ? cm : cz;
+                tx = (go && mx) ? t_new : tx;
+                ty = (go && my) ? t_new : ty;
+                tz = (go && mz) ? t_new : tz;
+                if (go) { lookup(); }
             }
 
             // ---- walkers: push up to kPushPerRound spheres of the current cell ----
