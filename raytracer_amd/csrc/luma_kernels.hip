@@ -1525,10 +1525,10 @@ bool sphere_parallel_scene(uint32_t n_spheres)
 }
 
 // FLAG_GRID launches whose rays from hit points walk the grid as a wave (render_kernel_sp<GRID>, wave_grid_walk)
-// instead of lane by lane (render_kernel<GRID>).  Measured on MI355X, 1080p x 16 spp, lane / wave kernel ms
-// (tools/grid_coop_sweep.py): 64 spheres 1.73 / 1.92, 320: 2.55 / 2.53, 1024: 3.77 / 2.93, 4096: 5.98 / 4.02,
-// 16384: 10.3 / 8.3, 262144: 12.6 / 11.4; at 2 spp the wave kernel's fixed cost (one resident set of large
-// workgroups) still shows at 320: 0.48 / 0.54.
+// instead of lane by lane (render_kernel<GRID>).  Measured on MI355X, 1080p, lane / wave kernel ms
+// (tools/grid_threshold_sweep.py, final kernels): at 16 spp 160 spheres 1.74 / 1.88, 250: 2.04 / 1.99, 400: 2.30 / 2.03,
+// 511: 2.46 / 2.07; at 2 spp the wave kernel's fixed cost (one resident set of large workgroups, ~0.5 ms per call
+// whatever the scene) still shows: 250: 0.40 / 0.50, 511: 0.47 / 0.50.  512 serves both.
 bool grid_wave_walk(uint32_t n_spheres)
 {
     return n_spheres >= kGridWaveWalkMin;
