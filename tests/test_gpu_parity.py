@@ -351,6 +351,24 @@ def test_grid_equals_linear_scan_on_a_config5_band(abi):
     assert frames["grid"][2].sphere_tests * 100 < frames["linear"][2].sphere_tests
 
 
+@pytest.mark.parametrize("n,flags", [(2000, 0), (8000, 2), (30000, 0), (70000, 2)])
+def test_grid_equals_linear_scan_at_every_residency_tier(abi, n, flags):
+    """640x360 x 3 spp: the wave-cooperative walk with everything in LDS (2000 spheres), the tables only (8000), nothing
+    (30000) and sphere indices beyond 16 bits (70000) against the linear scan of the same scene on the GPU (itself
+    checked against the oracle elsewhere): frames, accumulators and ray counts equal."""
+    W, H = 640, 360
+    frames = {}
+    for name, extra in (("linear", 0), ("grid", abi.FLAG_GRID)):
+        with abi.Context(0) as ctx:
+            ctx.set_scene(abi.synthetic_scene(n)); ctx.set_camera(abi.default_camera(W, H)); ctx.set_frame(W, H)
+            img, st = ctx.render(abi.make_params(W, H, spp=3, bounces=5, paths=1, samples=1, mode=1, flags=flags | extra, seed=SEED))
+            frames[name] = (img, ctx.read_accum(), st)
+    assert_frames_equal(frames["grid"][0], frames["linear"][0], f"grid against linear, n={n}")
+    assert np.array_equal(frames["grid"][1].view(np.uint32), frames["linear"][1].view(np.uint32))
+    assert frames["grid"][2].rays == frames["linear"][2].rays
+    assert frames["grid"][2].sphere_tests * 50 < frames["linear"][2].sphere_tests
+
+
 @pytest.mark.parametrize("kind,n", [("cluster_and_outliers", 600), ("line", 600), ("coincident", 600), ("shells", 600), ("flat", 600),
                                     # the wave-cooperative walk's other tiers: tables in LDS / everything in global memory
                                     ("cluster_and_outliers", 6000), ("coincident", 6000), ("flat", 7000),
