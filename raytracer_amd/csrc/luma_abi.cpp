@@ -193,8 +193,9 @@ luma::RenderArgs make_args(const luma_ctx* ctx, const luma_params* p, uint32_t* 
     a.mirror_is_frame = 0;
     a.counters = ctx->d_counters;
     a.tile_counter = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(ctx->d_counters) + kCounterBytes);
-    a.split = 1;
-    a.split_scratch = nullptr;
+    luma::apply_plan(a, luma::SplitPlan{}, nullptr);             // one lane per pixel until a plan says otherwise
+    a.fine_row0 = ctx->rows;
+    a.coarse_wgs = a.coarse_gx = a.fine_gx = 0;
     a.grid = ctx->grid;
     return a;
 }
@@ -297,9 +298,9 @@ int order_after_previous(luma_ctx* ctx, hipStream_t stream)
 
 constexpr size_t kMaxSplitBytes = size_t(2) << 30;
 
-size_t split_parking_bytes(const luma_ctx* ctx, uint32_t spp)
+luma::SplitPlan split_plan(const luma_ctx* ctx, uint32_t spp, bool grid, bool from_hit, size_t park_budget)
 {
-    return static_cast<size_t>(spp) * 3u * ctx->band_pixels() * sizeof(float);   // a slot per frame
+    return luma::plan_split(ctx->width, ctx->rows, spp, ctx->n_spheres, grid, from_hit, park_budget);
 }
 
 int grow_split_planes(luma_ctx* ctx, size_t need)
@@ -323,20 +324,15 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
     luma::RenderArgs args = make_args(ctx, p, target_dev);
     args.target_mirror = target_mirror;
     args.mirror_is_frame = mirror_is_frame ? 1u : 0u;
-    args.split = luma::choose_split(ctx->band_pixels(), p->spp, ctx->n_spheres, grid);
-    ctx->last_split_refused = false;
-    if (args.split > 1) {
-        const size_t need = split_parking_bytes(ctx, p->spp);
-        if (need > kMaxSplitBytes) {
-            args.split = 1;                                      // not worth 2 GiB of scratch; reported in luma_stats
-            ctx->last_split_refused = true;
-        } else if (need > ctx->split_bytes) {
-            // only when luma_hip_reserve was not called (or named fewer spp): the first such call pays
-            if (int rc = grow_split_planes(ctx, need)) { return rc; }
-            ctx->device_allocs++;
-        }
-        args.split_scratch = ctx->d_split;
+    // (more than 2 GiB of parking is not worth it: such calls run one lane per pixel, reported in luma_stats)
+    const luma::SplitPlan plan = split_plan(ctx, p->spp, grid, (p->flags & LUMA_FLAG_ORIGIN_FROM_HIT) != 0, kMaxSplitBytes);
+    ctx->last_split_refused = plan.refused;
+    if (plan.park_bytes > ctx->split_bytes) {
+        // only when luma_hip_reserve was not called (or named fewer spp): the first such call pays
+        if (int rc = grow_split_planes(ctx, plan.park_bytes)) { return rc; }
+        ctx->device_allocs++;
     }
+    luma::apply_plan(args, plan, ctx->d_split);
     ctx->last_split = args.split;
     if (luma::persistent_launch(ctx->n_spheres, grid)) {
         LUMA_HIP_TRY(hipMemsetAsync(args.tile_counter, 0, sizeof(uint32_t), stream));
@@ -681,9 +677,15 @@ int luma_hip_reserve(luma_ctx* ctx, uint32_t max_spp)
     DeviceScope scope(ctx->device);
     if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
     // the largest need over spp = 1 .. max_spp is at max_spp whenever frames are split at all
-    const uint32_t split = luma::choose_split(ctx->band_pixels(), max_spp, ctx->n_spheres, false);
-    const size_t need = split > 1 ? split_parking_bytes(ctx, max_spp) : 0;
-    if (need > kMaxSplitBytes || need <= ctx->split_bytes) { return LUMA_OK; }   // over the cap: such calls run one lane per pixel
+    // (whichever origin the bounce rays take: LUMA_FLAG_ORIGIN_FROM_HIT launches have no fine class)
+    size_t need = 0;
+    for (uint32_t spp = max_spp; spp >= 1 && spp + 8 > max_spp; spp--) {     // the fine class needs >= 8 spp: look a little below max_spp too
+        for (int from_hit = 0; from_hit < 2; from_hit++) {
+            const size_t bytes = split_plan(ctx, spp, false, from_hit != 0, kMaxSplitBytes).park_bytes;
+            if (bytes > need) { need = bytes; }
+        }
+    }
+    if (need <= ctx->split_bytes) { return LUMA_OK; }
     return grow_split_planes(ctx, need);
 }
 
@@ -752,10 +754,11 @@ int luma_hip_render_device_noalloc(luma_ctx* ctx, const luma_params* params, uin
     }
     const bool grid = false;
     // the scratch this call needs, against the fixed size of the static array
-    const uint32_t split = luma::choose_split(ctx->band_pixels(), params->spp, ctx->n_spheres, grid);
-    const unsigned long long parking = split > 1
-        ? static_cast<unsigned long long>(params->spp) * 3ull * ctx->band_pixels() * sizeof(float) : 0ull;
-    if (luma::kStaticCounterBytes + parking > luma::kStaticScratchBytes) {
+    // (a fine class whose parking does not fit is left out; frames split over the whole band must fit)
+    const luma::SplitPlan plan = split_plan(ctx, params->spp, grid, (params->flags & LUMA_FLAG_ORIGIN_FROM_HIT) != 0,
+                                            luma::kStaticScratchBytes - luma::kStaticCounterBytes);
+    const unsigned long long parking = plan.wanted_bytes;
+    if (plan.refused) {
         char msg[256];
         std::snprintf(msg, sizeof msg,
                       "spp %u x %zu band pixels needs %llu bytes of scratch, the static array holds %zu "
@@ -773,8 +776,7 @@ int luma_hip_render_device_noalloc(luma_ctx* ctx, const luma_params* params, uin
     unsigned char* const scratch = ctx->static_scratch;          // the device pointer, never the array's name
     args.counters = reinterpret_cast<unsigned long long*>(scratch);
     args.tile_counter = reinterpret_cast<uint32_t*>(scratch + kCounterBytes);
-    args.split = split;
-    args.split_scratch = split > 1 ? reinterpret_cast<float*>(scratch + luma::kStaticCounterBytes) : nullptr;
+    luma::apply_plan(args, plan, reinterpret_cast<float*>(scratch + luma::kStaticCounterBytes));
     // every call on this GPU shares the array and finds the previous call's contents in it: the
     // counters (the tile counter must start at zero) are cleared; the parking planes need no
     // clearing, every slot that is read was written earlier in the same launch

@@ -84,6 +84,11 @@ struct RenderArgs {
     // lanes 1.. park their frames: spp x 3 x band pixels floats (one slot per frame)
     uint32_t  split;
     float*    split_scratch;
+    // two classes of workgroups in one launch (SplitPlan): rows [0, fine_row0) with `split` lanes per pixel, dispatched
+    // first, rows [fine_row0, rows) with `fine` lanes per pixel; fine == 0: one class, fine_row0 == rows
+    uint32_t  fine, fine_row0;
+    uint32_t  coarse_wgs, coarse_gx, fine_gx;   // filled in by launch_render: workgroups of the coarse class, workgroups per row of each
+    uint32_t  park_row0, park_pixels;           // the parking planes cover rows [park_row0, rows): park_pixels pixels each
     uint32_t* tile_counter;        // sphere-parallel kernel: next wave tile, zeroed before every launch
     unsigned long long* counters;  // kCounterSlots x kCounterStride: [0] rays traced, [1] sphere tests; summed by the host
     GridArgs  grid;                // only read under FLAG_GRID
@@ -102,7 +107,21 @@ hipError_t static_scratch_address(void** ptr);
 size_t     scene_lds_bytes(uint32_t n_spheres);
 bool       sphere_parallel_scene(uint32_t n_spheres);
 bool       persistent_launch(uint32_t n_spheres, bool grid);
-uint32_t   choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid);
+// How a launch of the ray-per-lane kernel spreads the frames of a pixel over lanes (render_kernel, SPLIT / FINE)
+struct SplitPlan {
+    uint32_t split = 1;            // lanes per pixel (of the coarse class when there are two)
+    uint32_t fine = 0;             // lanes per pixel of the fine class, 0: none
+    uint32_t fine_row0 = 0;        // first band row of the fine class (== rows when none)
+    uint32_t park_row0 = 0;        // rows [park_row0, rows) have lanes that park frames
+    uint32_t park_pixels = 0;
+    size_t   park_bytes = 0;       // spp x 3 planes x park_pixels floats; 0: nothing parks
+    bool     refused = false;      // more than one lane per pixel was wanted, but its wanted_bytes of parking exceed the budget
+    size_t   wanted_bytes = 0;
+};
+// park_budget: the most parking memory the caller will provide; a fine class that does not fit is left out
+SplitPlan  plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit,
+                      size_t park_budget);
+void       apply_plan(RenderArgs& args, const SplitPlan& plan, float* parking);
 hipError_t launch_prepare_records(const float* cx, const float* cy, const float* cz, const float* rad,
                                   uint32_t n, const float pos[3], float4* records, hipStream_t stream);
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);

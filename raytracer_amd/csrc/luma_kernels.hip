@@ -20,6 +20,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 
@@ -561,11 +562,22 @@ enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 // (see `claim` below).
 // (GRID: the walk waits on dependent loads, so six waves per SIMD with ~40 B of spills beat four
 //  without: 2.93 -> 2.15 ms at 4096 spheres; five: 2.42, seven: 2.12 / 3.05 at 65536, eight: 2.60)
-template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT, bool GRID, int NS = 0>
+#ifdef LUMA_DBG_TIMELINE
+// debug builds only (tools/band_timeline.py): when and where every wave of the ray-per-lane kernel ran
+__device__ uint4 dbg_timeline[1u << 18];
+extern "C" int luma_dbg_timeline_copy(void* host, size_t bytes)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dbg_timeline), bytes);
+}
+#endif
+template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT, bool GRID, int NS = 0, int FINE = 0>
 __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const RenderArgs A)
 {
     // [0,n): camera-origin records; [n,2n): general records; then mat0[n] (float4), mat1[n] (float2)
     extern __shared__ float4 lds_rec[];
+#ifdef LUMA_DBG_TIMELINE
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
 
     const uint32_t n = A.n_spheres;
     const float4* rec_cam = A.records;
@@ -597,19 +609,48 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     }
 
     // lane -> pixel inside the wave tile; wave -> (frame block k, tile inside the workgroup)
+    constexpr bool SPL = SPLIT > 1 || FINE > 0;                  // frames of a pixel are claimed through LDS
     constexpr int TILE_H = 64 / TILE_W;
     constexpr int WPK = WAVES / SPLIT;                           // waves per frame block
     constexpr int WGX = wg_waves_x(WPK), WGY = WPK / WGX;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t k = wave / WPK, wv = wave % WPK;
-    const uint32_t x = blockIdx.x * (WGX * TILE_W) + (wv % WGX) * TILE_W + (lane % TILE_W);
-    const uint32_t yl = blockIdx.y * (WGY * TILE_H) + (wv / WGX) * TILE_H + (lane / TILE_W);
+    constexpr int WPKF = FINE ? WAVES / FINE : WPK;              // the same for the workgroups of the fine class
+    constexpr int WGXF = wg_waves_x(WPKF), WGYF = WPKF / WGXF;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = SPL ? (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : threadIdx.x >> 6;
+    uint32_t k, wv, x, yl;
+    bool live;
+    bool lone = !SPL;                                            // this workgroup has one lane per pixel: frames 0 .. spp-1, no claims
+    if (FINE) {
+        // one-dimensional grid: the coarse class first (rows [0, fine_row0), SPLIT lanes per pixel), then the
+        // fine one (rows [fine_row0, rows), FINE lanes per pixel); see plan_split
+        const uint32_t b = blockIdx.x;
+        const bool fine = b >= A.coarse_wgs;
+        lone = SPLIT == 1 && !fine;
+        const uint32_t bb = fine ? b - A.coarse_wgs : b, gx = fine ? A.fine_gx : A.coarse_gx;
+        const uint32_t by = bb / gx, bx = bb - by * gx;
+        if (fine) {
+            k = wave / WPKF; wv = wave % WPKF;
+            x = bx * (WGXF * TILE_W) + (wv % WGXF) * TILE_W + (lane % TILE_W);
+            yl = A.fine_row0 + by * (WGYF * TILE_H) + (wv / WGXF) * TILE_H + (lane / TILE_W);
+            live = (x < A.width) && (yl < A.rows);
+        } else {
+            k = wave / WPK; wv = wave % WPK;
+            x = bx * (WGX * TILE_W) + (wv % WGX) * TILE_W + (lane % TILE_W);
+            yl = by * (WGY * TILE_H) + (wv / WGX) * TILE_H + (lane / TILE_W);
+            live = (x < A.width) && (yl < A.fine_row0);
+        }
+    } else {
+        k = wave / WPK; wv = wave % WPK;
+        x = blockIdx.x * (WGX * TILE_W) + (wv % WGX) * TILE_W + (lane % TILE_W);
+        yl = blockIdx.y * (WGY * TILE_H) + (wv / WGX) * TILE_H + (lane / TILE_W);
+        live = (x < A.width) && (yl < A.rows);
+    }
     const uint32_t y = global_row(A, yl);
-    const bool live = (x < A.width) && (yl < A.rows);
 
     const uint32_t pixel = y * A.width + x;                      // global index: RNG is band independent (:399)
     const uint32_t local = yl * A.width + x;                     // index into the band's planes
-    const size_t npix = (size_t)A.rows * A.width;
+    const size_t npix = A.park_pixels;                           // the parking planes cover rows [park_row0, rows)
+    const uint32_t plocal = local - A.park_row0 * A.width;
     const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
     const uint32_t slots = 2u + A.paths;
     const bool pathtrace = A.mode == MODE_PATHTRACE;
@@ -634,14 +675,14 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
 
     // DOF pre-pass, :416-432.  Noise free, so it is the same for every frame of the call; with
     // SPLIT > 1 lane 0 of the pixel traces it and hands blur and gain to the others through LDS.
-    __shared__ float2 dof_shared[SPLIT > 1 ? WPK * 64 : 1];
+    __shared__ float2 dof_shared[SPL ? (WPK > WPKF ? WPK : WPKF) * 64 : 1];
     // Frames of a pixel are not dealt out in fixed blocks: its SPLIT lanes claim them one at a
     // time from one LDS word (low half: claims from the front, by lane 0; high half: claims from
     // the back, by the others).  Lane 0 takes frames 0, 1, 2, ... and adds them directly, the
     // others take spp-1, spp-2, ... and park them; a claim is good while front + back < spp, so
     // the two ends meet wherever the lanes' luck puts them and no lane waits on a slower sibling.
-    __shared__ uint32_t claim[SPLIT > 1 ? WPK * 64 : 1];
-    if (SPLIT > 1 && k == 0) { claim[wv * 64 + lane] = 0u; }
+    __shared__ uint32_t claim[SPL ? (WPK > WPKF ? WPK : WPKF) * 64 : 1];
+    if (SPL && k == 0) { claim[wv * 64 + lane] = 0u; }
     f3 dir0 = mk3(0.f, 0.f, -1.f);
     float blur = 0.f, gainf = 1.f;
     // The camera's matrices, and further down what only the epilogue needs, are read from the kernel-argument
@@ -660,9 +701,9 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
         const float focus = 1.0f - luma_expf(-x10);              // :427
         blur = fma_(focus, 4.5f, 0.5f);                          // :429-432
         gainf = (A.show_depth && (focus < .5f)) ? 1.2f : 1.0f;   // :448-452
-        if (SPLIT > 1) { dof_shared[wv * 64 + lane] = make_float2(blur, gainf); }
+        if (SPL) { dof_shared[wv * 64 + lane] = make_float2(blur, gainf); }
     }
-    if (SPLIT > 1) {
+    if (SPL) {
         __syncthreads();
         if (live && k != 0) { const float2 v = dof_shared[wv * 64 + lane]; blur = v.x; gainf = v.y; }
     }
@@ -673,25 +714,26 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     uint32_t front = 0;                                          // frames lane 0 added itself: [0, front)
 
     if (live) {
-        if (k == 0) { acc_r = A.acc[0][local]; acc_g = A.acc[1][local]; acc_b = A.acc[2][local]; }
+        if (k == 0) { acc_r = KA->acc[0][local]; acc_g = KA->acc[1][local]; acc_b = KA->acc[2][local]; }
 
         // per-lane path state (slot == bounce * slots: first RNG slot of the bounce)
-        uint32_t s = 0, bounce = 0, slot = 0;
+        uint32_t s = (FINE && lone) ? ~0u : 0u, bounce = 0, slot = 0;
         f3 direct = mk3(0.f, 0.f, 0.f);
         f3 dir = dir0;                                           // :293
         f3 origin = campos;                                      // :294, :303
 
         // next frame of this lane: s, or false when the pixel has none left
         auto next_frame = [&]() -> bool {
+            if (FINE && lone) { s++; return s < spp_all; }
             const uint32_t old = atomicAdd(&claim[wv * 64 + lane], k == 0 ? 1u : 0x10000u);
             const uint32_t f = old & 0xFFFFu, b = old >> 16;
             if (f + b >= spp_all) { return false; }
             s = (k == 0) ? f : spp_all - 1u - b;
             return true;
         };
-        bool have = (SPLIT == 1) ? true : next_frame();          // SPLIT == 1: plainly frames 0 .. spp-1
+        bool have = !SPL ? true : next_frame();                  // one lane per pixel everywhere: plainly frames 0 .. spp-1
 
-        while (SPLIT == 1 ? s < spp_all : have) {
+        while (!SPL ? s < spp_all : have) {
             const uint32_t sample = A.frame_index + s;
             f3 dn = dir;
             if (NOISE) { dn = add3(dir, rng_vec3(A, pixel, sample, slot, -blur, blur)); }   // :118-119, :302
@@ -761,14 +803,13 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
 
             if (path_ends) {
                 const f3 result = scale3(tonemap3(direct), gainf);    // :362, :57-70; :452 (x * 1.0f is x)
-                if (SPLIT == 1 || k == 0) {
+                if (!SPL || k == 0) {
                     acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
-                    if (SPLIT > 1) { front++; }
                 } else {
-                    float* park = A.split_scratch + (size_t)s * 3u * npix + local;
+                    float* park = KA->split_scratch + (size_t)s * 3u * npix + plocal;
                     park[0] = result.x; park[npix] = result.y; park[2 * npix] = result.z;
                 }
-                if (SPLIT == 1) { s++; } else { have = next_frame(); }
+                if (!SPL) { s++; } else { have = next_frame(); }
                 bounce = 0;
                 slot = 0;
                 direct = mk3(0.f, 0.f, 0.f);
@@ -778,11 +819,15 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
         }
     }
 
-    if (SPLIT > 1) { __syncthreads(); }                          // parked frames are visible to the workgroup
+    if (SPL) {
+        __syncthreads();                                         // parked frames are visible to the workgroup
+        // lane 0 of the pixel stopped at its first refused claim: its half of the word is one past its frames
+        front = (FINE && lone) ? spp_all : (claim[wv * 64 + lane] & 0xFFFFu) - 1u;
+    }
 
     const auto E = kernarg_args();                               // what only the epilogue needs, read here
     if (live && k == 0) {
-        if (SPLIT > 1) {
+        if (SPL) {
             // the other lanes' frames, added in frame order (:457-458); eight frames' loads are
             // issued together so the loop waits for memory once per eight frames, not per frame
             uint32_t f = front;
@@ -790,14 +835,14 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
                 float pr[8], pg[8], pb[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float* park = A.split_scratch + (size_t)(f + j) * 3u * npix + local;
+                    const float* park = E->split_scratch + (size_t)(f + j) * 3u * npix + plocal;
                     pr[j] = park[0]; pg[j] = park[npix]; pb[j] = park[2 * npix];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) { acc_r += pr[j]; acc_g += pg[j]; acc_b += pb[j]; }
             }
             for (; f < spp_all; f++) {
-                const float* park = A.split_scratch + (size_t)f * 3u * npix + local;
+                const float* park = E->split_scratch + (size_t)f * 3u * npix + plocal;
                 acc_r += park[0]; acc_g += park[npix]; acc_b += park[2 * npix];
             }
         }
@@ -817,6 +862,16 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
         if (mirror) { mirror[E->mirror_is_frame ? frame_pixel(E, local) : local] = px; }
     }
 
+#ifdef LUMA_DBG_TIMELINE
+    {
+        const unsigned long long dbg_t1 = wall_clock64();
+        const uint32_t w = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63u) == 0 && w < (1u << 18)) {
+            const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));
+            dbg_timeline[w] = make_uint4((uint32_t)dbg_t0, (uint32_t)dbg_t1, hw, xcc);
+        }
+    }
+#endif
     unsigned long long* const counters = E->counters;
     wave_add_u64(counters, nrays);
     if (GRID) { wave_add_u64(counters + 1, ntests); wave_add_u64(counters + 2, nrays); }   // tests, and rays of grid launches
@@ -1540,7 +1595,7 @@ bool persistent_launch(uint32_t n_spheres, bool grid)
     return grid ? grid_wave_walk(n_spheres) : sphere_parallel_scene(n_spheres);
 }
 
-uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid)
+static uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid)
 {
     if (persistent_launch(n_spheres, grid)) { return 1; }
     // measured on MI355X, bands of the 1080p x 64 spp frame (kernel ms for 1 / 2 / 4 lanes per pixel):
@@ -1552,6 +1607,66 @@ uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool
     // front can reach spp + 1 and the back spp + split - 1
     if (spp > 0x7FFFu) { split = 1; }
     return split ? split : 1u;
+}
+
+// The fine class.  Every workgroup of a launch carries the same number of frames, so when the dispatcher runs out
+// of workgroups the GPU drains for as long as one of them takes: 0.38 of the 1.80 ms of the 1080p x 64 spp frame were
+// spent at half occupancy on average (tools/band_timeline.py).  The last rows of the band are therefore cut into
+// workgroups of a quarter (half) the frames each, four lanes per pixel, dispatched after all the others: they fill
+// the slots the long workgroups leave and end within 0.11 ms of each other.  Kernel ms by share of rows in the
+// fine class (tools/fine_pct_sweep.sh), whole frame: 0 % 1.796, 8 % 1.754, 10 % 1.754, 12 % 1.760, 14 % 1.763,
+// 18 % 1.775, 26 % 1.792; band of 2 (two lanes per pixel above the fine rows): 0.975, 0.959, 0.955, 0.952, 0.954,
+// 0.960, 0.959.  Bands that already run four lanes per pixel gain nothing from eight in eight-wave workgroups
+// (band of 4: 0.513 against 0.506; the whole frame with eight: 1.79 at best) and keep one class.  Only the instances
+// with a compile-time sphere count have the class (scenes of up to 8 spheres, camera-origin bounce rays: launch_render).
+static bool fine_class_launch(uint32_t split, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit)
+{
+    return split <= 2 && spp >= 8 && spp <= 0x7FFFu && !grid && !from_hit && n_spheres >= 1 && n_spheres <= 8;
+}
+
+SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit,
+                     size_t park_budget)
+{
+    SplitPlan plan;
+    plan.fine_row0 = rows;
+    plan.split = choose_split((size_t)width * rows, spp, n_spheres, grid);
+    const size_t per_pixel = (size_t)spp * 3u * sizeof(float);   // a slot per frame in each of three planes
+    if (plan.split > 1) {
+        plan.wanted_bytes = per_pixel * width * rows;
+        if (plan.wanted_bytes > park_budget) {                   // one lane per pixel, nothing parks
+            plan.split = 1;
+            plan.refused = true;
+            return plan;
+        }
+    }
+    if (fine_class_launch(plan.split, spp, n_spheres, grid, from_hit)) {
+        uint32_t pct = plan.split == 1 ? 10u : 12u;
+#ifdef LUMA_SWEEP_FINE_PCT
+        if (const char* e = getenv("LUMA_FINE_PCT")) { pct = (uint32_t)atoi(e); }
+#endif
+        size_t fine_rows = ((size_t)rows * pct + 99u) / 100u;
+        // with one lane per pixel above them only the fine rows park: as many of them as the budget holds
+        if (plan.split == 1) { fine_rows = std::min(fine_rows, park_budget / (per_pixel * width)); }
+        const uint32_t row0 = (rows - (uint32_t)std::min<size_t>(fine_rows, rows) + 3u) & ~3u;   // whole coarse workgroups (4 rows each) above it
+        if (row0 < rows) {
+            plan.fine = 4;
+            plan.fine_row0 = row0;
+        }
+    }
+    plan.park_row0 = plan.split > 1 ? 0u : plan.fine_row0;
+    plan.park_pixels = (rows - plan.park_row0) * width;
+    plan.park_bytes = (plan.split > 1 || plan.fine) ? per_pixel * plan.park_pixels : 0;
+    return plan;
+}
+
+void apply_plan(RenderArgs& args, const SplitPlan& plan, float* parking)
+{
+    args.split = plan.split;
+    args.fine = plan.fine;
+    args.fine_row0 = plan.fine_row0;
+    args.park_row0 = plan.park_row0;
+    args.park_pixels = plan.park_pixels;
+    args.split_scratch = plan.park_bytes ? parking : nullptr;
 }
 
 // ---------------------------------------------------------------------------------
@@ -1615,7 +1730,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     const size_t sp_bytes = (size_t)((n + 63u) & ~63u) * 2u * sizeof(float4);
     kernel_t k;
     size_t lds;
-    int waves, split = 1;
+    int waves, split = 1, fine = 0;
     const bool use_grid = (args.flags & FLAG_GRID) != 0 && n > 0;
     const bool sphere_parallel = persistent_launch(n, use_grid);
     if (sphere_parallel && use_grid) {
@@ -1679,6 +1794,17 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 #undef LUMA_NS8
 #undef LUMA_NS
             k = ns_table[split == 4 ? 2 : split == 2 ? 1 : 0][n - 1][noise];
+            if (args.fine) {
+#define LUMA_NF(W, P, F, N) { render_kernel<kLaneTileW, W, SCENE_LDS_ALL, false, false, P, false, N, F>, \
+                              render_kernel<kLaneTileW, W, SCENE_LDS_ALL, true, false, P, false, N, F> }
+#define LUMA_NF8(W, P, F) { LUMA_NF(W, P, F, 1), LUMA_NF(W, P, F, 2), LUMA_NF(W, P, F, 3), LUMA_NF(W, P, F, 4), \
+                            LUMA_NF(W, P, F, 5), LUMA_NF(W, P, F, 6), LUMA_NF(W, P, F, 7), LUMA_NF(W, P, F, 8) }
+                static const kernel_t fine_table[2][8][2] = { LUMA_NF8(4, 1, 4), LUMA_NF8(4, 2, 4) };
+#undef LUMA_NF8
+#undef LUMA_NF
+                k = fine_table[split == 2][n - 1][noise];
+                fine = (int)args.fine;
+            }
         }
         if (use_grid) {                                          // records and materials stay in global memory
             // the grid's cell offsets go to LDS as 16-bit words when six workgroups' copies fit a CU
@@ -1691,6 +1817,16 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     const int wgx = wg_waves_x(wpk), wgy = wpk / wgx;
     const int tile_w = sphere_parallel ? kTileW : kLaneTileW, tile_h = 64 / tile_w;
     dim3 grid((args.width + wgx * tile_w - 1) / (wgx * tile_w), (rows + wgy * tile_h - 1) / (wgy * tile_h));
+    RenderArgs with_classes = args;
+    if (fine) {
+        // coarse workgroups first, then the fine ones, in one row of blocks (the dispatcher goes through it in order)
+        const int wpkf = waves / fine, wgxf = wg_waves_x(wpkf), wgyf = wpkf / wgxf;
+        const uint32_t fine_rows = rows - args.fine_row0;
+        with_classes.coarse_gx = grid.x;
+        with_classes.coarse_wgs = grid.x * (args.fine_row0 / (uint32_t)(wgy * tile_h));   // fine_row0 is a multiple of 4 rows
+        with_classes.fine_gx = (args.width + wgxf * tile_w - 1) / (wgxf * tile_w);
+        grid = dim3(with_classes.coarse_wgs + with_classes.fine_gx * ((fine_rows + wgyf * tile_h - 1) / (wgyf * tile_h)), 1);
+    }
     if (sphere_parallel) {
         // persistent waves: one resident set of workgroups, tiles handed out by a counter
         int cus = 256;
@@ -1707,7 +1843,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { return e; }
     }
-    hipLaunchKernelGGL(k, grid, dim3(waves * 64), lds, stream, args);
+    hipLaunchKernelGGL(k, grid, dim3(waves * 64), lds, stream, with_classes);
     return hipGetLastError();
 }
 

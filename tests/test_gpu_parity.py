@@ -457,6 +457,26 @@ def test_bands_equal_full_frame(abi, oracle, nbands):
     assert rays == fst.rays
 
 
+@pytest.mark.parametrize("W,H,spp,lanes", [(1603, 1001, 9, 1), (1201, 701, 13, 2), (1537, 977, 8, 1)])
+def test_two_classes_of_workgroups_equal_small_bands(abi, W, H, spp, lanes):
+    """Frames large enough for the fine class (luma_kernels.hip plan_split: the last rows of the launch run four
+    lanes per pixel, the rows above them `lanes`), with sides that are no multiple of the 32x2 wave tile or of the
+    four rows a coarse workgroup covers, against the same frame rendered as 11 uneven bands of four lanes per
+    pixel, which have one class."""
+    kw = dict(spp=spp, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+    full, facc, fst = hip_render(abi, abi.default_scene(), abi.default_camera(W, H), W, H, **kw)
+    assert fst.lanes_per_pixel == lanes
+    rays = 0
+    for b in range(11):
+        y0, y1 = b * H // 11, (b + 1) * H // 11
+        band, bacc, st = hip_render(abi, abi.default_scene(), abi.default_camera(W, H), W, H, rows=(y0, y1), **kw)
+        assert st.lanes_per_pixel == 4
+        assert_frames_equal(band, full[y0:y1], f"rows {y0}..{y1}")
+        assert np.array_equal(bacc.view(np.uint32), facc[y0:y1].view(np.uint32))
+        rays += st.rays
+    assert rays == fst.rays
+
+
 @pytest.mark.parametrize("W,H,stripe,n,scene_n", [(96, 48, 3, 4, 0), (64, 120, 15, 8, 0), (50, 32, 4, 2, 384)])
 def test_interleaved_stripes_equal_full_frame(abi, oracle, W, H, stripe, n, scene_n):
     """luma_hip_set_frame_striped: rank r renders rows with (y / stripe) % n == r; the stripes put

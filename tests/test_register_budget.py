@@ -1,7 +1,9 @@
-"""The headline kernel's register budget, checked where the library is built (no GPU needed): the config #3
-instance of the ray-per-lane kernel runs eight waves per SIMD only with at most 64 VGPRs and 80 SGPRs and no
-spills; one more live value in its loop costs a wave per SIMD and ~1.5 % (profiles/r02/
-ab_lazy_args.txt).  Compiles luma_kernels.hip to assembly once (about a minute) and reads the kernels' metadata."""
+"""The headline kernels' register budgets, checked where the library is built (no GPU needed).  The one-class
+config #3 instance of the ray-per-lane kernel runs eight waves per SIMD only with at most 64 VGPRs and 80 SGPRs
+and no spills; one more live value in its loop costs a wave per SIMD and ~1.5 % (profiles/r02/
+ab_lazy_args.txt).  The two-class instance that renders the whole config #3 frame (FINE = 4) was measured at seven
+waves per SIMD (72 VGPRs, 96 SGPRs) and must not spill: the no-allocation entry point launches it too.
+Compiles luma_kernels.hip to assembly once (about a minute) and reads the kernels' metadata."""
 import os
 import re
 import shutil
@@ -37,13 +39,23 @@ def test_makefile_flags_are_the_ones_checked():
 
 
 def test_config3_kernel_keeps_eight_waves_per_simd(kernel_metadata):
-    # render_kernel<TILE_W=32, WAVES=4, SCENE_LDS_ALL, NOISE, !FROM_HIT, SPLIT=1, !GRID, NS=5>
-    names = [n for n in kernel_metadata if re.search(r"render_kernelILi32ELi4ELi2ELb1ELb0ELi1ELb0ELi5E", n)]
+    # render_kernel<TILE_W=32, WAVES=4, SCENE_LDS_ALL, NOISE, !FROM_HIT, SPLIT=1, !GRID, NS=5, FINE=0>
+    names = [n for n in kernel_metadata if re.search(r"render_kernelILi32ELi4ELi2ELb1ELb0ELi1ELb0ELi5ELi0E", n)]
     assert len(names) == 1, names
     k = kernel_metadata[names[0]]
     assert k["vgpr_count"] <= 64, k
     assert k["sgpr_count"] <= 80, k
     assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
+
+
+def test_config3_two_class_kernel_keeps_seven_waves_per_simd(kernel_metadata):
+    # render_kernel<TILE_W=32, WAVES=4, SCENE_LDS_ALL, NOISE, !FROM_HIT, SPLIT=1 or 2, !GRID, NS=5, FINE=4>
+    names = [n for n in kernel_metadata if re.search(r"render_kernelILi32ELi4ELi2ELb1ELb0ELi[12]ELb0ELi5ELi4E", n)]
+    assert len(names) == 2, names
+    for name in names:
+        k = kernel_metadata[name]
+        assert k["vgpr_count"] <= 72 and k["sgpr_count"] <= 96, (name, k)
+        assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, (name, k)
 
 
 def test_kernels_behind_the_no_alloc_entry_point_use_no_private_memory(kernel_metadata):
