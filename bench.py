@@ -55,7 +55,10 @@ def measured_traffic(workload):
             continue
         entry = doc.get(workload, {})
         if entry.get("corrected_bytes") is not None:
-            return entry["corrected_bytes"], f"profiles/{rnd}/traffic.json @ {doc.get('commit', 'round-1 kernels (30d299c)')}"
+            src = f"profiles/{rnd}/traffic.json @ {doc.get('commit', 'round-1 kernels (30d299c)')}"
+            if entry.get("note"):
+                src += "; " + entry["note"]
+            return entry["corrected_bytes"], src
     return None, None
 
 

@@ -22,9 +22,7 @@ with abi.Context(0) as ctx:
     L.luma_dbg_timeline_copy.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
     rc = L.luma_dbg_timeline_copy(buf.ctypes.data, buf.nbytes)
     assert rc == 0, rc
-rows = H // N
-waves_per_wg = 8 if (N >= 3 and st.lanes_per_pixel == 4) else 4
-n_wg = ((W + 31) // 32) * ((rows + 1) // 2) if st.lanes_per_pixel == 4 else None
+waves_per_wg = 4
 used = buf[(buf[:, 0] != 0) | (buf[:, 1] != 0)]
 print("waves recorded:", len(used))
 t0 = used[:, 0].astype(np.int64); t1 = used[:, 1].astype(np.int64)
