@@ -1633,18 +1633,25 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
     const size_t per_pixel = (size_t)spp * 3u * sizeof(float);   // a slot per frame in each of three planes
     if (plan.split > 1) {
         plan.wanted_bytes = per_pixel * width * rows;
-        if (plan.wanted_bytes > park_budget) {                   // one lane per pixel, nothing parks
+        if (plan.wanted_bytes > park_budget) {                   // one lane per pixel (a fine class may still fit)
             plan.split = 1;
             plan.refused = true;
-            return plan;
         }
     }
     if (fine_class_launch(plan.split, spp, n_spheres, grid, from_hit)) {
-        uint32_t pct = plan.split == 1 ? 10u : 12u;
+        // The drain lasts one coarse workgroup and runs half empty on average, so the fine class should hold about
+        // half a round of the coarse waves: a share of 0.45 / rounds, where rounds = coarse waves / wave slots
+        // (256 CUs x 28; whole config #3 frame and its band of 2: 4.5 rounds, 10 %, the measured optimum above)
+        const double rounds = (double)width * rows / 64.0 * plan.split / (256.0 * 28.0);
+        double share = rounds > 0.0 ? 0.45 / rounds : 0.0;
+        // (from nine rounds up the drain is too small a part of the launch to pay for the parked frames: config #4's
+        //  whole frame, 18 rounds of 256 frames, 25.10 ms with one class, 25.48 with 2 % of its rows in a second;
+        //  one of its eight bands, 2.3 rounds: 3.74 -> 3.40, tools/fine_config4.sh)
+        share = share < 0.05 ? 0.0 : share > 0.30 ? 0.30 : share;
 #ifdef LUMA_SWEEP_FINE_PCT
-        if (const char* e = getenv("LUMA_FINE_PCT")) { pct = (uint32_t)atoi(e); }
+        if (const char* e = getenv("LUMA_FINE_PCT")) { share = atoi(e) / 100.0; }
 #endif
-        size_t fine_rows = ((size_t)rows * pct + 99u) / 100u;
+        size_t fine_rows = (size_t)((double)rows * share + 0.999);
         // with one lane per pixel above them only the fine rows park: as many of them as the budget holds
         if (plan.split == 1) { fine_rows = std::min(fine_rows, park_budget / (per_pixel * width)); }
         const uint32_t row0 = (rows - (uint32_t)std::min<size_t>(fine_rows, rows) + 3u) & ~3u;   // whole coarse workgroups (4 rows each) above it
