@@ -613,11 +613,17 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     constexpr int TILE_H = 64 / TILE_W;
     constexpr int WPK = WAVES / SPLIT;                           // waves per frame block
     constexpr int WGX = wg_waves_x(WPK), WGY = WPK / WGX;
-    constexpr int WPKF = FINE ? WAVES / FINE : WPK;              // the same for the workgroups of the fine class
+    // FINE > WAVES: a wave of the fine class holds FINE / WAVES lanes of each of its pixels, side by side
+    // (FINE = 8 in 4 waves: lanes 0-31 and 32-63 of a wave are two lanes of the same 32x1 pixels)
+    constexpr bool HALF = FINE > WAVES;
+    constexpr int LPW = HALF ? FINE / WAVES : 1;                 // lanes of one pixel in one wave
+    static_assert(!HALF || 64 / LPW == TILE_W, "a split wave of the fine class covers one row of a tile");
+    constexpr int WPKF = HALF ? 1 : FINE ? WAVES / FINE : WPK;   // waves per frame block in the workgroups of the fine class
     constexpr int WGXF = wg_waves_x(WPKF), WGYF = WPKF / WGXF;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = SPL ? (uint32_t)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : threadIdx.x >> 6;
     uint32_t k, wv, x, yl;
+    uint32_t cidx;                                               // the pixel's slot in dof_shared / claim
     bool live;
     bool lone = !SPL;                                            // this workgroup has one lane per pixel: frames 0 .. spp-1, no claims
     if (FINE) {
@@ -628,7 +634,12 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
         lone = SPLIT == 1 && !fine;
         const uint32_t bb = fine ? b - A.coarse_wgs : b, gx = fine ? A.fine_gx : A.coarse_gx;
         const uint32_t by = bb / gx, bx = bb - by * gx;
-        if (fine) {
+        if (fine && HALF) {
+            k = wave * LPW + lane / TILE_W; wv = 0;
+            x = bx * TILE_W + (lane % TILE_W);
+            yl = A.fine_row0 + by;
+            live = (x < A.width) && (yl < A.rows);
+        } else if (fine) {
             k = wave / WPKF; wv = wave % WPKF;
             x = bx * (WGXF * TILE_W) + (wv % WGXF) * TILE_W + (lane % TILE_W);
             yl = A.fine_row0 + by * (WGYF * TILE_H) + (wv / WGXF) * TILE_H + (lane / TILE_W);
@@ -639,11 +650,13 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
             yl = by * (WGY * TILE_H) + (wv / WGX) * TILE_H + (lane / TILE_W);
             live = (x < A.width) && (yl < A.fine_row0);
         }
+        cidx = (fine && HALF) ? lane % TILE_W : wv * 64 + lane;
     } else {
         k = wave / WPK; wv = wave % WPK;
         x = blockIdx.x * (WGX * TILE_W) + (wv % WGX) * TILE_W + (lane % TILE_W);
         yl = blockIdx.y * (WGY * TILE_H) + (wv / WGX) * TILE_H + (lane / TILE_W);
         live = (x < A.width) && (yl < A.rows);
+        cidx = wv * 64 + lane;
     }
     const uint32_t y = global_row(A, yl);
 
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     // others take spp-1, spp-2, ... and park them; a claim is good while front + back < spp, so
     // the two ends meet wherever the lanes' luck puts them and no lane waits on a slower sibling.
     __shared__ uint32_t claim[SPL ? (WPK > WPKF ? WPK : WPKF) * 64 : 1];
-    if (SPL && k == 0) { claim[wv * 64 + lane] = 0u; }
+    if (SPL && k == 0) { claim[cidx] = 0u; }
     f3 dir0 = mk3(0.f, 0.f, -1.f);
     float blur = 0.f, gainf = 1.f;
     // The camera's matrices, and further down what only the epilogue needs, are read from the kernel-argument
@@ -701,11 +714,11 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
         const float focus = 1.0f - luma_expf(-x10);              // :427
         blur = fma_(focus, 4.5f, 0.5f);                          // :429-432
         gainf = (A.show_depth && (focus < .5f)) ? 1.2f : 1.0f;   // :448-452
-        if (SPL) { dof_shared[wv * 64 + lane] = make_float2(blur, gainf); }
+        if (SPL) { dof_shared[cidx] = make_float2(blur, gainf); }
     }
     if (SPL) {
         __syncthreads();
-        if (live && k != 0) { const float2 v = dof_shared[wv * 64 + lane]; blur = v.x; gainf = v.y; }
+        if (live && k != 0) { const float2 v = dof_shared[cidx]; blur = v.x; gainf = v.y; }
     }
 
     // bounces == 0: the loop at :300 never runs, every sample adds tonemap(0) * gain = +0.
@@ -725,7 +738,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
         // next frame of this lane: s, or false when the pixel has none left
         auto next_frame = [&]() -> bool {
             if (FINE && lone) { s++; return s < spp_all; }
-            const uint32_t old = atomicAdd(&claim[wv * 64 + lane], k == 0 ? 1u : 0x10000u);
+            const uint32_t old = atomicAdd(&claim[cidx], k == 0 ? 1u : 0x10000u);
             const uint32_t f = old & 0xFFFFu, b = old >> 16;
             if (f + b >= spp_all) { return false; }
             s = (k == 0) ? f : spp_all - 1u - b;
@@ -822,7 +835,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
     if (SPL) {
         __syncthreads();                                         // parked frames are visible to the workgroup
         // lane 0 of the pixel stopped at its first refused claim: its half of the word is one past its frames
-        front = (FINE && lone) ? spp_all : (claim[wv * 64 + lane] & 0xFFFFu) - 1u;
+        front = (FINE && lone) ? spp_all : (claim[cidx] & 0xFFFFu) - 1u;
     }
 
     const auto E = kernarg_args();                               // what only the epilogue needs, read here
@@ -1621,7 +1634,7 @@ static uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_sphere
 // with a compile-time sphere count have the class (scenes of up to 8 spheres, camera-origin bounce rays: launch_render).
 static bool fine_class_launch(uint32_t split, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit)
 {
-    return split <= 2 && spp >= 8 && spp <= 0x7FFFu && !grid && !from_hit && n_spheres >= 1 && n_spheres <= 8;
+    return split <= 4 && spp >= 8 && spp <= 0x7FFFu && !grid && !from_hit && n_spheres >= 1 && n_spheres <= 8;
 }
 
 SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit,
@@ -1648,6 +1661,12 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
         //  whole frame, 18 rounds of 256 frames, 25.10 ms with one class, 25.48 with 2 % of its rows in a second;
         //  one of its eight bands, 2.3 rounds: 3.74 -> 3.40, tools/fine_config4.sh)
         share = share < 0.05 ? 0.0 : share > 0.30 ? 0.30 : share;
+        // Four lanes per pixel above: eight in the fine class, two of each pixel side by side in every wave of a
+        // four-wave workgroup (HALF in render_kernel; eight-wave workgroups lose more than the class gains).  Those
+        // workgroups cost more per frame, and a few of them are enough to fill the drain of 0.1 ms workgroups:
+        // bands of 4 / 8 of the config #3 frame 0.507 / 0.278 ms with one class, 0.497 / 0.275 with 2 % of the rows
+        // in the class, 0.496 / 0.264 with 5 %, 0.498 / 0.266 with 10 %, 0.502 / 0.267 with 20 % (tools/fine8_share_sweep.sh)
+        if (plan.split == 4) { share = 0.05; }
 #ifdef LUMA_SWEEP_FINE_PCT
         if (const char* e = getenv("LUMA_FINE_PCT")) { share = atoi(e) / 100.0; }
 #endif
@@ -1656,7 +1675,10 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
         if (plan.split == 1) { fine_rows = std::min(fine_rows, park_budget / (per_pixel * width)); }
         const uint32_t row0 = (rows - (uint32_t)std::min<size_t>(fine_rows, rows) + 3u) & ~3u;   // whole coarse workgroups (4 rows each) above it
         if (row0 < rows) {
-            plan.fine = 4;
+            plan.fine = plan.split == 4 ? 8 : 4;
+#ifdef LUMA_SWEEP_FINE_PCT
+            if (const char* e = getenv("LUMA_FINE_LANES")) { plan.fine = (uint32_t)atoi(e); }
+#endif
             plan.fine_row0 = row0;
         }
     }
@@ -1806,11 +1828,21 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
                               render_kernel<kLaneTileW, W, SCENE_LDS_ALL, true, false, P, false, N, F> }
 #define LUMA_NF8(W, P, F) { LUMA_NF(W, P, F, 1), LUMA_NF(W, P, F, 2), LUMA_NF(W, P, F, 3), LUMA_NF(W, P, F, 4), \
                             LUMA_NF(W, P, F, 5), LUMA_NF(W, P, F, 6), LUMA_NF(W, P, F, 7), LUMA_NF(W, P, F, 8) }
-                static const kernel_t fine_table[2][8][2] = { LUMA_NF8(4, 1, 4), LUMA_NF8(4, 2, 4) };
+                static const kernel_t fine_table[3][8][2] = { LUMA_NF8(4, 1, 4), LUMA_NF8(4, 2, 4), LUMA_NF8(4, 4, 8) };
+                k = fine_table[split == 4 ? 2 : split == 2 ? 1 : 0][n - 1][noise];
+#ifdef LUMA_SWEEP_FINE_PCT
+                if (args.fine == 8 && split < 4 && n == 5) {     // sweep builds: eight lanes under one or two
+                    static const kernel_t f8[2][2] = { LUMA_NF(4, 1, 8, 5), LUMA_NF(4, 2, 8, 5) };
+                    k = f8[split == 2][noise];
+                }
+                if (args.fine == 4 && split == 4 && n == 5) {    // and a fine class of the same four lanes: same kernel as one class
+                    static const kernel_t f4[2] = LUMA_NF(4, 4, 4, 5);
+                    k = f4[noise];
+                }
+#endif
+                fine = (int)args.fine;
 #undef LUMA_NF8
 #undef LUMA_NF
-                k = fine_table[split == 2][n - 1][noise];
-                fine = (int)args.fine;
             }
         }
         if (use_grid) {                                          // records and materials stay in global memory
@@ -1827,12 +1859,15 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     RenderArgs with_classes = args;
     if (fine) {
         // coarse workgroups first, then the fine ones, in one row of blocks (the dispatcher goes through it in order)
-        const int wpkf = waves / fine, wgxf = wg_waves_x(wpkf), wgyf = wpkf / wgxf;
+        // (more lanes per pixel than waves: a workgroup of the fine class is one row of one tile, see HALF)
+        const bool half = fine > waves;
+        const int wpkf = half ? 1 : waves / fine, wgxf = wg_waves_x(wpkf), wgyf = wpkf / wgxf;
+        const int fine_tile_h = half ? 1 : tile_h;
         const uint32_t fine_rows = rows - args.fine_row0;
         with_classes.coarse_gx = grid.x;
         with_classes.coarse_wgs = grid.x * (args.fine_row0 / (uint32_t)(wgy * tile_h));   // fine_row0 is a multiple of 4 rows
         with_classes.fine_gx = (args.width + wgxf * tile_w - 1) / (wgxf * tile_w);
-        grid = dim3(with_classes.coarse_wgs + with_classes.fine_gx * ((fine_rows + wgyf * tile_h - 1) / (wgyf * tile_h)), 1);
+        grid = dim3(with_classes.coarse_wgs + with_classes.fine_gx * ((fine_rows + wgyf * fine_tile_h - 1) / (wgyf * fine_tile_h)), 1);
     }
     if (sphere_parallel) {
         // persistent waves: one resident set of workgroups, tiles handed out by a counter

@@ -459,10 +459,10 @@ def test_bands_equal_full_frame(abi, oracle, nbands):
 
 @pytest.mark.parametrize("W,H,spp,lanes", [(1603, 1001, 9, 1), (1201, 701, 13, 2), (1537, 977, 8, 1)])
 def test_two_classes_of_workgroups_equal_small_bands(abi, W, H, spp, lanes):
-    """Frames large enough for the fine class (luma_kernels.hip plan_split: the last rows of the launch run four
-    lanes per pixel, the rows above them `lanes`), with sides that are no multiple of the 32x2 wave tile or of the
-    four rows a coarse workgroup covers, against the same frame rendered as 11 uneven bands of four lanes per
-    pixel, which have one class."""
+    """Frames large enough for the fine class above one or two lanes per pixel (luma_kernels.hip plan_split: the last
+    rows of the launch run four lanes per pixel, the rows above them `lanes`), with sides that are no multiple of
+    the 32x2 wave tile or of the four rows a coarse workgroup covers, against the same frame rendered as 11 uneven
+    bands (four lanes per pixel and their own fine class of eight: test_fine_class_of_eight_lanes_vs_oracle)."""
     kw = dict(spp=spp, bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
     full, facc, fst = hip_render(abi, abi.default_scene(), abi.default_camera(W, H), W, H, **kw)
     assert fst.lanes_per_pixel == lanes
@@ -475,6 +475,19 @@ def test_two_classes_of_workgroups_equal_small_bands(abi, W, H, spp, lanes):
         assert np.array_equal(bacc.view(np.uint32), facc[y0:y1].view(np.uint32))
         rays += st.rays
     assert rays == fst.rays
+
+
+@pytest.mark.parametrize("W,H,spp,noise_off", [(333, 77, 9, 0), (96, 64, 8, 0), (257, 130, 17, 1), (31, 9, 64, 0)])
+def test_fine_class_of_eight_lanes_vs_oracle(abi, oracle, W, H, spp, noise_off):
+    """Small frames run four lanes per pixel and, from 8 spp, eight in their last rows (two lanes of each pixel side
+    by side in a wave, 32x1 pixels per workgroup): whole frames against the oracle, accumulator included."""
+    kw = dict(spp=spp, bounces=5, paths=1, samples=1, mode=1, flags=noise_off, seed=SEED)
+    got, acc, st = hip_render(abi, abi.default_scene(), abi.default_camera(W, H), W, H, **kw)
+    assert st.lanes_per_pixel == 4
+    r = oracle.Renderer(oracle.default_scene(), oracle.camera(W, H), W, H)
+    r.render(oracle.make_params(W, H, **kw))
+    assert_frames_equal(got, r.target, "fine class of eight lanes")
+    assert np.array_equal(acc.view(np.uint32), r.accum.view(np.uint32))
 
 
 @pytest.mark.parametrize("W,H,stripe,n,scene_n", [(96, 48, 3, 4, 0), (64, 120, 15, 8, 0), (50, 32, 4, 2, 384)])

@@ -1,0 +1,11 @@
+#!/bin/bash
+# tools/fine_lanes_sweep.sh -- kernel ms of the config #3 frame and its bands of 2 / 4 / 8 by lanes per pixel of the fine
+# class (LUMA_FINE_LANES) and its share of the rows (LUMA_FINE_PCT), in a build with -DLUMA_SWEEP_FINE_PCT (ab/fine_sweep.so)
+pp='import json,sys; d=json.loads(sys.stdin.read()); print(round(d["kernel_ms"],4), end=" ")'
+for lanes in 4 8; do
+for pct in "$@"; do
+  echo -n "fine lanes $lanes share $pct %: "
+  for w in 1 2 4 8; do LUMA_HIP_LIB=$PWD/ab/fine_sweep.so LUMA_FINE_LANES=$lanes LUMA_FINE_PCT=$pct timeout -k 10 100 python bench.py --emulate-world $w --steps 100 --warmup 10 --no-cpu-baseline --no-frame-leg 2>/dev/null | python -c "$pp"; done
+  echo
+done
+done
