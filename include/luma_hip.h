@@ -93,7 +93,8 @@ typedef struct {
     uint64_t rays;          /* trace_ray invocations executed (Renderer.cpp:234) */
     uint64_t sphere_tests;  /* ray-sphere tests executed (loop at Renderer.cpp:242) */
     /* How the latest launch used the GPU (no counterpart in the reference): lanes that shared one
-     * pixel's frames (1, 2 or 4; small bands of small scenes use several), and 1 in
+     * pixel's frames (1, 2 or 4; small bands of small scenes use several; the last rows
+     * of a launch may run more of them, its "fine class", which this number does not show), and 1 in
      * split_refused when it ran one lane per pixel only because the planes in which the extra lanes
      * park their frames (spp * 12 B * band pixels) would have passed 2 GiB. */
     uint32_t lanes_per_pixel;
@@ -133,8 +134,9 @@ int luma_hip_set_frame_striped(luma_ctx* ctx, uint32_t width, uint32_t height, u
                                uint32_t rank, uint32_t n_ranks);
 
 /* Set-up for render calls of up to max_spp frames on the current scene and frame: allocates now
- * whatever device scratch such calls use (the planes in which small bands park frames rendered by
- * several lanes of one pixel), so that luma_hip_render* itself never allocates or synchronises the
+ * whatever device scratch such calls use (the planes in which small bands, and the last rows of
+ * large ones, park frames rendered by several lanes of one pixel: spp * 12 B per such pixel, 153 MB
+ * for a 1080p frame of 64 spp, 199 MB for an eighth of it), so that luma_hip_render* itself never allocates or synchronises the
  * device for it.  Optional: without it the first render call that needs more scratch than the
  * context holds allocates it.  Call again after luma_hip_set_frame* / luma_hip_set_scene.
  * luma_hip_alloc_count reports how many device allocations render calls have made on the context
@@ -173,8 +175,8 @@ int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* t
  * without waiting (no luma_stats: its rays are not added to the context's counters).
  * Limits: a call whose scratch need exceeds the array is rejected with LUMA_E_ARG and a message
  * giving both sizes (need = 32 KiB + spp * 12 B * band pixels for bands under 1.5 M pixels of scenes
- * under 320 spheres, 32 KiB otherwise): render the frames in several calls of fewer spp, which
- * accumulates to the same bits.  LUMA_FLAG_GRID is rejected (LUMA_E_ARG): its tables are allocated
+ * under 320 spheres, 32 KiB otherwise; larger bands park only their last rows, as many as fit the
+ * array): render the frames in several calls of fewer spp, which accumulates to the same bits.  LUMA_FLAG_GRID is rejected (LUMA_E_ARG): its tables are allocated
  * on first use and its kernels spill registers, which makes the HIP runtime set up memory of its
  * own at dispatch; the kernels behind every other flag use no private memory.  All calls
  * on one GPU share the array, from any context: two such calls that overlap in time on one GPU race;

@@ -83,6 +83,20 @@ def test_noalloc_equals_render_device_two_calls_second_smaller(abi):
         ref.close(); new.close()
 
 
+def test_noalloc_large_band_parks_only_its_last_rows(abi):
+    # 1920x1080: one lane per pixel, and the last rows of the launch four (the fine class), whose
+    # frames park in the static array: as many rows as fit it at 64 spp (45 of the 108 the other entry point uses),
+    # all 108 at 16 spp.  Same bits as luma_hip_render_device either way.
+    W, H = 1920, 1080
+    ref, new = _pair(abi, abi.default_scene(), W, H)
+    try:
+        kw = dict(bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
+        _check_call(abi, ref, new, W, H, "1080p x64", check_mem=False, spp=64, **kw)
+        _check_call(abi, ref, new, W, H, "1080p x16 (accumulating)", spp=16, **kw)
+    finally:
+        ref.close(); new.close()
+
+
 def test_noalloc_large_scene_tile_counter(abi):
     # 512 spheres: the sphere-parallel kernel pulls tiles from the tile counter in the static array
     scene = abi.synthetic_scene(512, SEED)
