@@ -677,13 +677,11 @@ int luma_hip_reserve(luma_ctx* ctx, uint32_t max_spp)
     DeviceScope scope(ctx->device);
     if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
     // the largest need over spp = 1 .. max_spp is at max_spp whenever frames are split at all
-    // (whichever origin the bounce rays take: LUMA_FLAG_ORIGIN_FROM_HIT launches have no fine class)
+    // (parking grows with spp: what max_spp needs covers every call of fewer; LUMA_FLAG_ORIGIN_FROM_HIT launches
+    //  have no fine class, so the other kind is the larger)
     size_t need = 0;
-    for (uint32_t spp = max_spp; spp >= 1 && spp + 8 > max_spp; spp--) {     // the fine class needs >= 8 spp: look a little below max_spp too
-        for (int from_hit = 0; from_hit < 2; from_hit++) {
-            const size_t bytes = split_plan(ctx, spp, false, from_hit != 0, kMaxSplitBytes).park_bytes;
-            if (bytes > need) { need = bytes; }
-        }
+    for (int from_hit = 0; from_hit < 2; from_hit++) {
+        need = std::max(need, split_plan(ctx, max_spp, false, from_hit != 0, kMaxSplitBytes).park_bytes);
     }
     if (need <= ctx->split_bytes) { return LUMA_OK; }
     return grow_split_planes(ctx, need);

@@ -1368,21 +1368,32 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = (A.width + TILE_W - 1) / TILE_W, tiles_y = (A.rows + TILE_H - 1) / TILE_H;
     const uint32_t n_tiles = tiles_x * tiles_y;
+    // The last tiles are handed out one row (TILE_W pixels) at a time: a wave scans for one ray at a time whatever
+    // the number of its pixels, so a row costs a quarter of a tile, and the launch drains for a quarter as long.
+    // About half a round of the resident waves; a frame of fewer tiles than that goes row by row throughout.
+    // Config #5 band 153.8 -> 150.6 ms, 640x360 x 16 spp of 2000 spheres 7.26 -> 5.12 (tools/ab_config5_both.sh).  Not
+    // under GRID: a wave walks the grid for all its rays together, and a quarter of the rays is less than a quarter
+    // of the work (the same band 5.99 -> 6.31 ms, the small frame 0.60 -> 0.93).
+    const uint32_t tail = GRID ? 0u : min(n_tiles, (gridDim.x * WAVES) / 2u);
+    const uint32_t n_whole = n_tiles - tail, n_items = n_whole + tail * TILE_H;
     const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
     const uint32_t slots = 2u + A.paths;
     const bool pathtrace = A.mode == MODE_PATHTRACE;
     uint32_t nrays = 0;
 
   for (;;) {
-    uint32_t tile = 0;
-    if (lane == 0) { tile = atomicAdd(A.tile_counter, 1u); }
-    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-    if (tile >= n_tiles) { break; }                              // every wave reaches this: the counter only grows
+    uint32_t item = 0;
+    if (lane == 0) { item = atomicAdd(A.tile_counter, 1u); }
+    item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+    if (item >= n_items) { break; }                              // every wave reaches this: the counter only grows
+    const bool by_row = item >= n_whole;
+    const uint32_t tile = by_row ? n_whole + (item - n_whole) / TILE_H : item;
+    const uint32_t row = by_row ? (item - n_whole) % TILE_H : 0u;
 
     const uint32_t x = (tile % tiles_x) * TILE_W + (lane % TILE_W);
     const uint32_t yl = (tile / tiles_x) * TILE_H + (lane / TILE_W);
     const uint32_t y = global_row(A, yl);
-    const bool live = (x < A.width) && (yl < A.rows);
+    const bool live = (x < A.width) && (yl < A.rows) && (!by_row || lane / TILE_W == row);
 
     const uint32_t pixel = y * A.width + x;                      // global index (:399); unused when !live
     const uint32_t local = yl * A.width + x;
@@ -1877,7 +1888,8 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         const size_t by_lds = (160u * 1024u) / (lds ? lds : 1);
         const size_t per_cu = std::max<size_t>(1, std::min<size_t>(32 / waves, by_lds));
         const uint32_t n_tiles = ((args.width + tile_w - 1) / tile_w) * ((rows + tile_h - 1) / tile_h);
-        const size_t want = (n_tiles + waves - 1) / waves;
+        // (small frames are handed out row by row by the linear-scan kernel: render_kernel_sp)
+        const size_t want = ((size_t)n_tiles * (use_grid ? 1 : tile_h) + waves - 1) / waves;
         grid = dim3((unsigned)std::max<size_t>(1, std::min<size_t>(want, per_cu * (size_t)cus)), 1);
     }
     if (lds > 64 * 1024) {
