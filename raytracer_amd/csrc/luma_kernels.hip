@@ -560,6 +560,11 @@ enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 // frame order, so the float sum is still the reference's ((acc + f0) + f1) + ...
 // (Renderer.cpp:457-458), bit for bit.  Which lane renders which frame is settled at run time
 // (see `claim` below).
+// FINE (0: none; 4 or 8) gives the launch a second class of workgroups: the band's last rows, from
+// RenderArgs::fine_row0 on, run FINE lanes per pixel in workgroups dispatched after all the others, so
+// that the launch does not drain for as long as one of the long workgroups takes (plan_split has the
+// measurements).  With FINE the grid is one-dimensional; the coarse class (SPLIT lanes per pixel, a plain
+// frame loop without claims when SPLIT == 1) comes first in it.
 // (GRID: the walk waits on dependent loads, so six waves per SIMD with ~40 B of spills beat four
 //  without: 2.93 -> 2.15 ms at 4096 spheres; five: 2.42, seven: 2.12 / 3.05 at 65536, eight: 2.60)
 #ifdef LUMA_DBG_TIMELINE
