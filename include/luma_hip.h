@@ -316,6 +316,20 @@ int luma_view_grid_describe(const luma_sphere* spheres, uint32_t n, const float 
                             uint32_t* n_items, uint32_t* n_large, uint32_t* cell_start, uint32_t* items,
                             uint32_t* large);
 
+/* Host-only view of how a render call of the ray-per-lane kernel would spread the frames of a pixel over lanes
+ * (no GPU work; for tests and tuning; no counterpart in the reference): for a band of `rows` x `width`
+ * pixels, `spp` frames per call, a scene of `n_spheres`, with or without LUMA_FLAG_GRID, and at most
+ * `park_budget` bytes for the planes in which lanes park frames.  lanes / fine_lanes: lanes per pixel in rows
+ * [0, fine_row0) and [fine_row0, rows) (fine_lanes 0: one class, fine_row0 == rows); rows [park_row0, rows)
+ * park frames, park_bytes in all; refused: more lanes were wanted than the budget allows. */
+typedef struct {
+    uint32_t lanes, fine_lanes, fine_row0, park_row0;
+    uint64_t park_bytes;
+    uint32_t refused;
+} luma_split_plan;
+int luma_split_plan_describe(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_spheres, uint32_t flags,
+                             uint64_t park_budget, luma_split_plan* plan);
+
 /* ---- diagnostics --------------------------------------------------------------- */
 const char* luma_hip_strerror(int code);
 const char* luma_hip_last_error(void);   /* thread-local text of the last failure */

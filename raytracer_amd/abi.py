@@ -31,7 +31,13 @@ SYMBOLS = [
     "luma_hip_render_device_noalloc",
     "luma_hip_group_render_device", "luma_hip_group_frame_device", "luma_hip_group_read_frame",
     "luma_hip_reserve", "luma_hip_alloc_count", "luma_hip_group_reserve", "luma_view_grid_describe",
+    "luma_split_plan_describe",
 ]
+
+
+class SplitPlan(C.Structure):
+    _fields_ = [("lanes", C.c_uint32), ("fine_lanes", C.c_uint32), ("fine_row0", C.c_uint32), ("park_row0", C.c_uint32),
+                ("park_bytes", C.c_uint64), ("refused", C.c_uint32)]
 
 
 class Sphere(C.Structure):
@@ -126,6 +132,7 @@ def lib():
         "luma_hip_host_free": (None, [C.c_void_p]),
         "luma_grid_describe": (C.c_int, [C.POINTER(Sphere), C.c_uint32, C.POINTER(GridInfo), u32p, u32p, u32p]),
         "luma_view_grid_describe": (C.c_int, [C.POINTER(Sphere), C.c_uint32, f32p, u32p, u32p, u32p, u32p, u32p, u32p]),
+        "luma_split_plan_describe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(SplitPlan)]),
         "luma_hip_strerror": (C.c_char_p, [C.c_int]),
         "luma_hip_last_error": (C.c_char_p, []),
         "luma_hip_abi_version": (C.c_int, []),
@@ -231,6 +238,13 @@ def describe_view_grid(spheres, origin):
     check(lib().luma_view_grid_describe(spheres if n else None, n, _f32p(o), C.byref(res), C.byref(n_items), C.byref(n_large),
                                         _u32p(cell_start), _u32p(items), _u32p(large)), "luma_view_grid_describe")
     return res.value, cell_start, items[:n_items.value], large[:n_large.value]
+
+
+def split_plan(width, rows, spp, n_spheres, flags=0, park_budget=2 << 30):
+    """luma_split_plan_describe: how a render call would spread a pixel's frames over lanes (host-only)."""
+    plan = SplitPlan()
+    check(lib().luma_split_plan_describe(width, rows, spp, n_spheres, flags, park_budget, C.byref(plan)), "luma_split_plan_describe")
+    return plan
 
 
 def device_count():

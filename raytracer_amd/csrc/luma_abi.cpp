@@ -1382,6 +1382,23 @@ int luma_grid_describe(const luma_sphere* spheres, uint32_t n, luma_grid_info* i
     return LUMA_OK;
 }
 
+int luma_split_plan_describe(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_spheres, uint32_t flags,
+                             uint64_t park_budget, luma_split_plan* plan)
+{
+    if (!plan) { return fail(LUMA_E_ARG, "luma_split_plan_describe", "null argument"); }
+    if (width == 0 || rows == 0 || spp == 0) { return fail(LUMA_E_ARG, "luma_split_plan_describe", "width, rows and spp must be >= 1"); }
+    const bool grid = (flags & LUMA_FLAG_GRID) != 0 && n_spheres > 0;
+    const luma::SplitPlan p = luma::plan_split(width, rows, spp, n_spheres, grid, (flags & LUMA_FLAG_ORIGIN_FROM_HIT) != 0,
+                                               static_cast<size_t>(park_budget));
+    plan->lanes = p.split;
+    plan->fine_lanes = p.fine;
+    plan->fine_row0 = p.fine_row0;
+    plan->park_row0 = p.park_row0;
+    plan->park_bytes = p.park_bytes;
+    plan->refused = p.refused ? 1u : 0u;
+    return LUMA_OK;
+}
+
 int luma_view_grid_describe(const luma_sphere* spheres, uint32_t n, const float origin[3], uint32_t* res,
                             uint32_t* n_items, uint32_t* n_large, uint32_t* cell_start, uint32_t* items, uint32_t* large)
 {
