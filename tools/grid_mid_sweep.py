@@ -1,3 +1,6 @@
+"""LUMA_FLAG_GRID kernel ms, tests per ray and Mrays/s at 1080p x 16 spp for scenes of 4096 - 16384 spheres: the sizes
+at which the wave walk's tables leave LDS (residency tiers of render_kernel_sp<GRID>).  One line per scene; LUMA_HIP_LIB
+names the build.  Run on the GPU box from the repo root."""
 import os, sys; sys.path.insert(0, '.')
 from raytracer_amd import abi
 W, H = 1920, 1080

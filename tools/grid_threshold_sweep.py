@@ -1,3 +1,6 @@
+"""LUMA_FLAG_GRID kernel ms at 1080p, 2 and 16 spp, for scenes of 64 - 511 spheres: builds with kGridWaveWalkMin at 512
+(lane-per-ray walk for all of them) and at 1 (wave walk) give the crossover quoted at grid_wave_walk().  One line per
+spp; LUMA_HIP_LIB names the build.  Run on the GPU box from the repo root."""
 import os, sys; sys.path.insert(0, '.')
 from raytracer_amd import abi
 W, H = 1920, 1080
