@@ -1689,7 +1689,10 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
         size_t fine_rows = (size_t)((double)rows * share + 0.999);
         // with one lane per pixel above them only the fine rows park: as many of them as the budget holds
         if (plan.split == 1) { fine_rows = std::min(fine_rows, park_budget / (per_pixel * width)); }
-        const uint32_t row0 = (rows - (uint32_t)std::min<size_t>(fine_rows, rows) + 3u) & ~3u;   // whole coarse workgroups (4 rows each) above it
+        // whole coarse workgroups (4 rows each) above the class: rounded towards fewer fine rows where their parking is
+        // what the budget limits, towards more where the whole band parks anyway
+        const uint32_t above = rows - (uint32_t)std::min<size_t>(fine_rows, rows);
+        const uint32_t row0 = plan.split == 1 ? (above + 3u) & ~3u : above & ~3u;
         if (row0 < rows) {
             plan.fine = plan.split == 4 ? 8 : 4;
 #ifdef LUMA_SWEEP_FINE_PCT

@@ -103,6 +103,18 @@ for n in range(1, 9):
             pitch=float(_rng.uniform(-0.5, 0.5)), yaw=float(_rng.uniform(-1, 1)), calls=2))
 
 
+# the same sphere counts at 8 spp and more: the last rows of these launches form the fine class (eight lanes per
+# pixel, two of each pixel side by side in a wave; luma_kernels.hip plan_split, HALF), frames accumulating over two calls
+for n in range(1, 9):
+    kind = ["mirror", "cluster", "wide", "around"][n % 4]
+    CASES.append(dict(
+        id=f"fine{n}-{kind}", kind=kind, n=n, scale=1.0, seed=int(_rng.integers(1, 2**31)),
+        W=int(_rng.integers(20, 70)), H=int(_rng.integers(21, 46)), spp=int(_rng.choice([8, 9, 13, 20])),
+        bounces=int(_rng.integers(1, 7)), paths=int(_rng.integers(0, 3)), samples=1, mode=1, flags=int(n % 2),
+        rng_seed=int(_rng.integers(0, 2**63)), posed=bool(n % 3 == 0), pos=[float(v) for v in _rng.uniform(-2, 2, size=3)],
+        pitch=float(_rng.uniform(-0.5, 0.5)), yaw=float(_rng.uniform(-1, 1)), calls=2))
+
+
 @pytest.mark.parametrize("c", CASES, ids=[c["id"] for c in CASES])
 def test_random_scene_matches_oracle(abi, oracle, c):
     rng = np.random.default_rng(c["seed"])
