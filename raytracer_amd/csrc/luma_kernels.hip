@@ -1900,6 +1900,10 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         const size_t want = ((size_t)n_tiles * (use_grid ? 1 : tile_h) + waves - 1) / waves;
         grid = dim3((unsigned)std::max<size_t>(1, std::min<size_t>(want, per_cu * (size_t)cus)), 1);
     }
+#ifdef LUMA_SWEEP_FINE_PCT
+    // sweep builds: unused LDS per workgroup, to hold fewer waves per SIMD than the registers allow (occupancy probe)
+    if (const char* e = getenv("LUMA_LDS_PAD_KB")) { lds += (size_t)atoi(e) * 1024u; }
+#endif
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
