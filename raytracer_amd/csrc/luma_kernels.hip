@@ -901,8 +901,8 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
 // With thousands of spheres the scan is >99 % of the work and "one lane = one ray" wastes it
 // twice: lanes whose path has ended (or that have no indirect ray this step) idle through a
 // whole N-sphere scan, and every lane re-reads the same record.  Here the scan is turned
-// around: the wave takes ONE ray at a time, broadcasts it to SGPRs (v_readlane), and its 64
-// lanes test 64 DIFFERENT spheres per instruction, reading 1 KiB of records per ds_read_b128
+// around: the wave takes ONE ray at a time (four in large scenes, see wave_scan_many), broadcasts it to SGPRs
+// (v_readlane), and its 64 lanes test 64 DIFFERENT spheres per instruction, reading 1 KiB of records per ds_read_b128
 // (conflict free: 16 B per lane, contiguous).  Every lane does useful work on every scan
 // instruction whatever the divergence of the paths; rays that do not exist are simply not
 // scanned.  Each lane keeps the best (t, index) among its own spheres (its indices ascend, so
@@ -984,9 +984,89 @@ LUMA_DEV unsigned long long wave_scan_one(const float4* __restrict__ rec, uint32
     return ((unsigned long long)t_min << 32) | i_min;
 }
 
-// Scans the ray of every lane with want == true (one after the other) and returns, in that
+// Scan for up to R rays at once (cnt of them, broadcast to SGPRs by the caller) over records laid out
+// [batch][lane] in LDS; n_pad is a multiple of 64 and the padding records are NaN (never a candidate).  All 64
+// lanes must call this.  Every record a lane reads is tested against all the rays: per ray the arithmetic, its
+// order and the candidates are the same whatever R, so the results are the same bits.  Rays per pass, kernel ms
+// (tools/scan_rays_ab.sh): config #5 band 147.9 / 141.6 / 139.4 / 137.9 for R = 1 / 2 / 3 / 4, 1080p x 4 spp of
+// 5000 spheres 25.5 / 24.0 / 23.5 / 23.2, of 1100: 6.57 / 6.30 / 6.26 / 6.20; of 320 and 640 (four-wave workgroups,
+// five per CU while the kernel keeps to 96 VGPRs): 3.26 / 3.33 / 3.29 / 3.32 and 4.31 / 4.41 / 4.43 / 4.38.  So four
+// rays in the 16-wave workgroups of large scenes, one in the others (render_kernel_sp; R == 1 goes through
+// wave_scan_one, 3 % faster at 640 spheres than this function with one ray).
+template <bool CAM_ORIGIN, int R>
+LUMA_DEV void wave_scan_many(const float4* __restrict__ rec, uint32_t n_pad, uint32_t lane, uint32_t cnt,
+                             const float (&ox)[R], const float (&oy)[R], const float (&oz)[R],
+                             const float (&dx)[R], const float (&dy)[R], const float (&dz)[R], const float (&a)[R],
+                             unsigned long long (&key)[R])
+{
+    float best_t[R];
+    uint32_t best_i[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) { best_t[r] = FLT_MAX; best_i[r] = 0xFFFFFFFFu; }   // :236-238
+
+    auto test = [&](int r, const float4 s, float& b, float& d) {
+        float c;
+        if (CAM_ORIGIN) {
+            b = fma_(s.z, dz[r], fma_(s.y, dy[r], s.x * dx[r]));  // :247 (half), diff precomputed
+            c = s.w;
+        } else {
+            const float fx = ox[r] - s.x, fy = oy[r] - s.y, fz = oz[r] - s.z;   // :244
+            b = fma_(fz, dz[r], fma_(fy, dy[r], fx * dx[r]));
+            c = fma_(-s.w, s.w, fma_(fz, fz, fma_(fy, fy, fx * fx)));  // :248
+        }
+        d = fma_(b, b, -(a[r] * c));                             // :251 (quarter)
+    };
+    auto consider = [&](int r, float b, float d, uint32_t i) {
+        if (d > 0.0f && b < 0.0f) {                              // :253 (b >= 0 gives t <= 0, rejected at :258)
+            const float t = (-b - sqrt_rn(d)) / a[r];            // :255
+            if (t > 0.0f && t < best_t[r]) { best_t[r] = t; best_i[r] = i; }   // :258, :266
+        }
+    };
+
+    uint32_t base = 0;
+    for (; base + 256 <= n_pad; base += 256) {
+        const float4 s0 = rec[base + lane], s1 = rec[base + 64 + lane];
+        const float4 s2 = rec[base + 128 + lane], s3 = rec[base + 192 + lane];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (R == 1 || (uint32_t)r < cnt) {                             // wave-uniform
+                float b0, d0, b1, d1, b2, d2, b3, d3;
+                test(r, s0, b0, d0); test(r, s1, b1, d1); test(r, s2, b2, d2); test(r, s3, b3, d3);
+                const float any = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, -b0), __builtin_fminf(d1, -b1)),
+                                                  __builtin_fmaxf(__builtin_fminf(d2, -b2), __builtin_fminf(d3, -b3)));
+                if (any > 0.0f) {
+                    consider(r, b0, d0, base + lane); consider(r, b1, d1, base + 64 + lane);
+                    consider(r, b2, d2, base + 128 + lane); consider(r, b3, d3, base + 192 + lane);
+                }
+            }
+        }
+    }
+    for (; base < n_pad; base += 64) {                           // up to three more batches of 64
+        const float4 s0 = rec[base + lane];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if (R == 1 || (uint32_t)r < cnt) {
+                float b, d;
+                test(r, s0, b, d);
+                consider(r, b, d, base + lane);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        key[r] = ~0ull;
+        if (R == 1 || (uint32_t)r < cnt) {                                 // the lexicographic minimum of (t, index)
+            const uint32_t t_min = wave_min_u32(__builtin_bit_cast(uint32_t, best_t[r]));
+            const uint32_t i_min = wave_min_u32(__builtin_bit_cast(uint32_t, best_t[r]) == t_min ? best_i[r] : 0xFFFFFFFFu);
+            key[r] = ((unsigned long long)t_min << 32) | i_min;
+        }
+    }
+}
+
+// Scans the ray of every lane with want == true (R at a time) and returns, in that
 // lane, the closest hit (index or -1, and t).  Wave-uniform control flow: every lane calls it.
-template <bool CAM_ORIGIN>
+template <bool CAM_ORIGIN, int R>
 LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t lane, bool want,
                         f3 origin, f3 dir, int& idx, float& t)
 {
@@ -994,23 +1074,30 @@ LUMA_DEV void wave_scan(const float4* __restrict__ rec, uint32_t n_pad, uint32_t
     idx = -1;
     t = FLT_MAX;
     unsigned long long todo = __builtin_amdgcn_ballot_w64(want);
+    auto from_lane = [](float v, int j) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j)); };
     while (todo) {
-        const int j = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const float dx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dir.x), j));
-        const float dy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dir.y), j));
-        const float dz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dir.z), j));
-        const float aj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), j));
-        float ox = 0.f, oy = 0.f, oz = 0.f;
-        if (!CAM_ORIGIN) {
-            ox = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, origin.x), j));
-            oy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, origin.y), j));
-            oz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, origin.z), j));
+        int j[R];
+        uint32_t cnt = 0;
+        float ox[R], oy[R], oz[R], dx[R], dy[R], dz[R], aj[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            j[r] = todo ? __builtin_ctzll(todo) : j[0];          // (past cnt: lane j[0] again, not scanned)
+            cnt += todo ? 1u : 0u;
+            todo &= todo - 1;
+            dx[r] = from_lane(dir.x, j[r]); dy[r] = from_lane(dir.y, j[r]); dz[r] = from_lane(dir.z, j[r]);
+            aj[r] = from_lane(a, j[r]);
+            ox[r] = oy[r] = oz[r] = 0.f;
+            if (!CAM_ORIGIN) { ox[r] = from_lane(origin.x, j[r]); oy[r] = from_lane(origin.y, j[r]); oz[r] = from_lane(origin.z, j[r]); }
         }
-        const unsigned long long key = wave_scan_one<CAM_ORIGIN>(rec, n_pad, lane, ox, oy, oz, dx, dy, dz, aj);
-        if (lane == (uint32_t)j && (uint32_t)key != 0xFFFFFFFFu) {
-            idx = (int)(uint32_t)key;
-            t = __builtin_bit_cast(float, (uint32_t)(key >> 32));
+        unsigned long long key[R];
+        if constexpr (R == 1) { key[0] = wave_scan_one<CAM_ORIGIN>(rec, n_pad, lane, ox[0], oy[0], oz[0], dx[0], dy[0], dz[0], aj[0]); }
+        else { wave_scan_many<CAM_ORIGIN, R>(rec, n_pad, lane, cnt, ox, oy, oz, dx, dy, dz, aj, key); }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            if ((R == 1 || (uint32_t)r < cnt) && lane == (uint32_t)j[r] && (uint32_t)key[r] != 0xFFFFFFFFu) {
+                idx = (int)(uint32_t)key[r];
+                t = __builtin_bit_cast(float, (uint32_t)(key[r] >> 32));
+            }
         }
     }
 }
@@ -1346,6 +1433,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     }
     uint32_t ntests = 0;
     // Renderer::trace_ray (:234-287) for the wave: a ray from camera.pos / from anywhere, for the lanes that `want` one
+    constexpr int kScanRays = (WAVES == 16) ? 4 : 1;             // rays per pass of the linear scan (wave_scan_many)
     auto scan_cam = [&](bool want, f3 o, f3 d, int& idx, float& t) {
         if (GRID) {
             idx = -1;
@@ -1355,14 +1443,14 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
                 idx = RES == 2 ? scan_view<true>(G, rec_gen, o, d, t, ntests) : scan_view<false>(G, rec_cam, o, d, t, ntests);
             }
         } else {
-            wave_scan<true>(rec_cam, n_pad, lane_of_wave(), want, o, d, idx, t);
+            wave_scan<true, kScanRays>(rec_cam, n_pad, lane_of_wave(), want, o, d, idx, t);
         }
     };
     auto scan_gen = [&](bool want, f3 o, f3 d, int& idx, float& t) {
         if (GRID) {
             wave_grid_walk<(RES != 0)>(kernarg_grid(), grid_cells, grid_items, rec_gen, xch, lane_of_wave(), want, o, d, idx, t, ntests);
         }
-        else      { wave_scan<false>(rec_gen, n_pad, lane_of_wave(), want, o, d, idx, t); }
+        else      { wave_scan<false, kScanRays>(rec_gen, n_pad, lane_of_wave(), want, o, d, idx, t); }
     };
 
     // Persistent waves: the grid is one resident set of workgroups (the 128-KiB record image
@@ -1373,7 +1461,7 @@ __global__ __launch_bounds__(WAVES * 64) void render_kernel_sp(const RenderArgs 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t tiles_x = (A.width + TILE_W - 1) / TILE_W, tiles_y = (A.rows + TILE_H - 1) / TILE_H;
     const uint32_t n_tiles = tiles_x * tiles_y;
-    // The last tiles are handed out one row (TILE_W pixels) at a time: a wave scans for one ray at a time whatever
+    // The last tiles are handed out one row (TILE_W pixels) at a time: a wave scans for a few rays at a time whatever
     // the number of its pixels, so a row costs a quarter of a tile, and the launch drains for a quarter as long.
     // About half a round of the resident waves; a frame of fewer tiles than that goes row by row throughout.
     // Config #5 band 153.8 -> 150.6 ms, 640x360 x 16 spp of 2000 spheres 7.26 -> 5.12 (tools/ab_config5_both.sh).  Not
