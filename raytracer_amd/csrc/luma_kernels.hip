@@ -993,6 +993,7 @@ LUMA_DEV unsigned long long wave_scan_one(const float4* __restrict__ rec, uint32
 // five per CU while the kernel keeps to 96 VGPRs): 3.26 / 3.33 / 3.29 / 3.32 and 4.31 / 4.41 / 4.43 / 4.38.  So four
 // rays in the 16-wave workgroups of large scenes, one in the others (render_kernel_sp; R == 1 goes through
 // wave_scan_one, 3 % faster at 640 spheres than this function with one ray).
+// (Six / eight rays in the 16-wave workgroups: 137.1 / 136.1 ms against 137.7, and 6.31 / 6.35 against 6.17 at 1100.)
 template <bool CAM_ORIGIN, int R>
 LUMA_DEV void wave_scan_many(const float4* __restrict__ rec, uint32_t n_pad, uint32_t lane, uint32_t cnt,
                              const float (&ox)[R], const float (&oy)[R], const float (&oz)[R],
