@@ -9,7 +9,10 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("LUMA_HIP_LIB") or os.path.join(_PKG, "libluma_hip.so")   # override: A/B runs of two builds
+# A/B runs of two builds name the other one in LUMA_HIP_LIB; it is honoured only together with LUMA_AB=1, so
+# that a stray variable can never make tests or the bench load something other than the in-tree library
+_AB = os.environ.get("LUMA_HIP_LIB") if os.environ.get("LUMA_AB") == "1" else None
+LIB_PATH = _AB or os.path.join(_PKG, "libluma_hip.so")
 
 OK, E_ARG, E_HIP, E_NOMEM, E_STATE, E_RCCL = 0, -1, -2, -3, -4, -5
 MODE_RAYTRACE, MODE_PATHTRACE = 0, 1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export LUMA_AB=1   # abi.py honours LUMA_HIP_LIB only with this
 # tools/ab_config3.sh LIB... -- kernel ms of builds of libluma_hip.so on config #3 (whole frame), interleaved, 2 rounds
 pp='import json,sys; d=json.loads(sys.stdin.read()); print(round(d["kernel_ms"],4), end=" ")'
 for rep in 1 2; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export LUMA_AB=1   # abi.py honours LUMA_HIP_LIB only with this
 # tools/ab_config5.sh LIB... -- kernel ms of builds of libluma_hip.so on one of config #5's eight bands, interleaved, 2 rounds
 pp='import json,sys; d=json.loads(sys.stdin.read()); print(round(d["kernel_ms"],3), end=" ")'
 for rep in 1 2; do

@@ -1,4 +1,5 @@
 #!/bin/bash
+export LUMA_AB=1   # abi.py honours LUMA_HIP_LIB only with this
 # tools/fine8_share_sweep.sh -- kernel ms (two runs each) of the config #3 frame's bands of 4 and 8 by the share of rows in a
 # fine class of eight lanes per pixel, in a build with -DLUMA_SWEEP_FINE_PCT (ab/fine_sweep.so)
 pp='import json,sys; d=json.loads(sys.stdin.read()); print(round(d["kernel_ms"],4), end=" ")'

@@ -1,4 +1,5 @@
 #!/bin/bash
+export LUMA_AB=1   # abi.py honours LUMA_HIP_LIB only with this
 # tools/fine_config4.sh -- config #4 (3840x2160, 256 spp): whole frame and one of its eight bands, one class (ab/cur.so)
 # against two classes by share of rows (ab/fine_sweep.so, LUMA_FINE_PCT) and the library's own choice
 pp='import json,sys; d=json.loads(sys.stdin.read()); print(round(d["kernel_ms"],4), end=" ")'

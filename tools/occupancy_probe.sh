@@ -1,4 +1,5 @@
 #!/bin/bash
+export LUMA_AB=1   # abi.py honours LUMA_HIP_LIB only with this
 # tools/occupancy_probe.sh -- kernel ms of the config #3 frame with fewer waves per SIMD than its registers allow: unused LDS
 # per workgroup (LUMA_LDS_PAD_KB, builds with -DLUMA_SWEEP_FINE_PCT: ab/fine_sweep.so) limits the 4-wave workgroups per CU
 # (160 KiB LDS: 0 KB -> 7 by registers, 24 -> 6, 30 -> 5, 38 -> 4, 50 -> 3, 70 -> 2)

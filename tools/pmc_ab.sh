@@ -1,4 +1,5 @@
 #!/bin/bash
+export LUMA_AB=1   # abi.py honours LUMA_HIP_LIB only with this
 # tools/pmc_ab.sh OUTDIR LIB... -- the 'mix' and 'time' PMC passes of tools/pmc_passes.sh for each build of
 # libluma_hip.so named (LUMA_HIP_LIB), summaries side by side.  Run on the GPU box from the repo root.
 set -u

@@ -1,4 +1,5 @@
 #!/bin/bash
+export LUMA_AB=1   # abi.py honours LUMA_HIP_LIB only with this
 # tools/profile_grid.sh OUTDIR [OLD_LIB] -- evidence for LUMA_FLAG_GRID, on the GPU box from the repo root: where the
 # time of one of config #5's eight bands goes (tools/grid_split_probe.py), kernel time by scene size
 # (tools/grid_coop_sweep.py), rocprofv3 --kernel-trace --stats and the PMC passes of that band under bench.py --grid.

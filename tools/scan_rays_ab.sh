@@ -1,4 +1,5 @@
 #!/bin/bash
+export LUMA_AB=1   # abi.py honours LUMA_HIP_LIB only with this
 # tools/scan_rays_ab.sh LIB... -- builds with -DLUMA_SCAN_RAYS=R (rays per pass of the sphere-parallel scan): kernel ms of one
 # of config #5's eight bands (linear scan), of 1080p x 4 spp frames of 320 / 640 / 1100 / 2000 / 5000 spheres, one line per build
 pp='import json,sys; d=json.loads(sys.stdin.read()); print(round(d["kernel_ms"],3), end=" ")'
