@@ -896,6 +896,256 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
 }
 
 // ---------------------------------------------------------------------------------
+// The wavefront form of the ray-per-lane kernel (round 3): ONE wave owns P pixels (P > 64) and runs
+// the steps of their paths in two separate, full-width phases instead of one divergent loop body.
+//
+// Why.  In render_kernel a lane's (sample, bounce) step hits a sphere with probability ~0.38, decided by the
+// reference's +-blur direction noise (Renderer.cpp:302), so the ~250-instruction hit side (hit point, normal,
+// indirect ray and its scan, shading, reflection) runs on nearly every trip of a wave for 38 % of its lanes and
+// the sky / tonemap side for the other 62 %: 44 % active lanes per VALU instruction at the VALU issue limit
+// (profiles/r02/config3_pmc_summary.txt).  Pooling the hits of a whole workgroup cost more in barriers than it
+// saved (profiles/r02/ab_compacted_hits_rejected.txt).  A wave needs no barrier to talk to itself.
+//
+// How.  The state of every path (direction, radiance so far, frame and bounce numbers, the pixel's accumulator)
+// lives in the wave's own LDS, 64 B per pixel; the wave keeps two FIFO queues of pixel slots there:
+//   ready: paths whose next step is "draw the noise, scan the spheres from camera.pos" (phase A, :302-319;
+//          a path that ended is first tonemapped, added to its pixel and restarted as the next frame, :362, :457)
+//   hit:   paths that found a sphere and need the hit side (phase C, :321-359)
+// Each trip of the wave runs ONE phase on the 64 oldest entries of one queue -- every lane busy -- and pushes the
+// slots onto the queue of their next phase (ballot + mbcnt, no atomics).  With P = 128 paths in flight one of the
+// two queues always holds 64 entries until the wave's last pixels run out of frames.  A pixel has one path in flight
+// at a time, so its frames are still added in frame order (:457-458) and every path's arithmetic is the same
+// instruction sequence as in render_kernel: bit-identical frames.
+// ---------------------------------------------------------------------------------
+template <int P, bool NOISE, int NS>
+__global__ __launch_bounds__(64) void render_kernel_wf(const RenderArgs A)
+{
+    static_assert(P % 64 == 0 && P >= 128 && P <= 256, "slots are 8 bits of a queue entry; a wave's tile is 32 x (P / 32) pixels");
+    static_assert(NS >= 1 && NS <= 8, "the sphere index is 3 bits of a queue entry");
+    extern __shared__ float4 lds_rec[];
+    float4* const S0 = lds_rec;                 // accumulator rgb, state word (frame, bounce, flags)
+    float4* const S1 = lds_rec + P;             // direction of the next step, or after phase A the noised direction, and t
+    float4* const S2 = lds_rec + 2 * P;         // the pixel's camera ray (camera.rays[index]), blur
+    float4* const S3 = lds_rec + 3 * P;         // radiance of the path so far (`direct`, :298), global pixel index
+    float4* const l_mat0 = lds_rec + 4 * P;     // [8]
+    float4* const l_gen = l_mat0 + 8;           // [8] general records (centre, radius), for the hit point's normal
+    float2* const l_mat1 = reinterpret_cast<float2*>(l_gen + 8);           // [8]
+    constexpr uint32_t QCAP = P <= 128 ? 128u : 256u;                       // ring size: a power of two >= P
+    uint16_t* const readyQ = reinterpret_cast<uint16_t*>(l_mat1 + 8);      // [QCAP] ring
+    uint16_t* const hitQ = readyQ + QCAP;                                   // [QCAP] ring
+    constexpr uint32_t kEnded = 1u << 29, kGain = 1u << 30;                // state word: frame [0,16), bounce [16,29)
+
+    const uint32_t lane = threadIdx.x;
+    if (lane < (uint32_t)NS) { l_mat0[lane] = A.mat0[lane]; l_mat1[lane] = A.mat1[lane]; l_gen[lane] = A.records[NS + lane]; }
+    const float4* rec_gen = l_gen;
+    const f3 campos = mk3(A.cam_pos[0], A.cam_pos[1], A.cam_pos[2]);
+    const uint32_t slots = 2u + A.paths;
+    const bool pathtrace = A.mode == MODE_PATHTRACE;
+    const uint32_t spp_all = A.bounces ? A.spp : 0u;
+    uint32_t nrays = 0;
+    uint32_t rhead = 0, rtail = 0, hhead = 0, htail = 0;        // free-running; wave-uniform
+
+    auto closest_cam = [&](f3 o, f3 d, float& t) { return scan_spheres<true, false, NS>((LUMA_SCALAR_PTR)A.records, (uint32_t)NS, o, d, t); };
+    auto closest_gen = [&](f3 o, f3 d, float& t) { return scan_spheres<false, false, NS>((LUMA_SCALAR_PTR)(A.records + NS), (uint32_t)NS, o, d, t); };
+    // entry -> the queue's tail, for the lanes with `pred`, in lane order (every lane of the wave calls this)
+    auto push = [&](uint16_t* q, uint32_t& tail, bool pred, uint32_t entry) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(pred);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (pred) { q[(tail + rank) & (QCAP - 1u)] = (uint16_t)entry; }
+        tail += (uint32_t)__builtin_popcountll(m);
+    };
+
+    // the wave's tile: 32 pixels wide, P / 32 rows; slot = row in the tile * 32 + column
+    const uint32_t tiles_x = (A.width + 31u) / 32u;
+    const uint32_t ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const auto KA = kernarg_args();
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+    for (uint32_t j = 0; j < (uint32_t)(P / 64); j++) {
+        const uint32_t slot = j * 64u + lane;
+        const uint32_t x = tx * 32u + (slot & 31u), yl = ty * (uint32_t)(P / 32) + (slot >> 5);
+        const bool live = (x < A.width) && (yl < A.rows);
+        if (live) {
+            const uint32_t y = global_row(A, yl);
+            const uint32_t local = yl * A.width + x;
+            const f3 dir0 = camera_ray(KA, x, y);                // camera.rays[index], :413
+            float t0;                                            // DOF pre-pass, :416-432
+            const int h0 = closest_cam(campos, dir0, t0);
+            nrays++;
+            const float depth = (h0 >= 0) ? t0 : FLT_MAX;
+            const float dd = depth - A.focus_depth;
+            const float x2 = dd * dd, x4 = x2 * x2, x8 = x4 * x4, x10 = x8 * x2;
+            const float focus = 1.0f - luma_expf(-x10);
+            const float blur = fma_(focus, 4.5f, 0.5f);
+            const uint32_t sb = (A.show_depth && (focus < .5f)) ? kGain : 0u;
+            S0[slot] = make_float4(KA->acc[0][local], KA->acc[1][local], KA->acc[2][local], __builtin_bit_cast(float, sb));
+            S1[slot] = make_float4(dir0.x, dir0.y, dir0.z, 0.f);
+            S2[slot] = make_float4(dir0.x, dir0.y, dir0.z, blur);
+            S3[slot] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, y * A.width + x));
+        }
+        push(readyQ, rtail, live && spp_all > 0u, slot);
+    }
+
+#pragma unroll 1
+    for (;;) {
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t rc = rtail - rhead, hc = htail - hhead;
+        bool hit_phase;
+        uint32_t n;
+        if (hc >= 64u)            { hit_phase = true;  n = 64u; }
+        else if (rc >= 64u)       { hit_phase = false; n = 64u; }
+        else if ((rc | hc) == 0u) { break; }
+        else if (rc >= hc)        { hit_phase = false; n = rc; }   // the wave's last pixels: whichever queue holds more
+        else                      { hit_phase = true;  n = hc; }
+
+        if (!hit_phase) {
+            // ---- phase A: [finish the path that ended, start the pixel's next frame], noise, scan from camera.pos ----
+            uint32_t slot = 0;
+            int idx = -1;
+            bool alive = false;
+            if (lane < n) {
+                slot = readyQ[(rhead + lane) & (QCAP - 1u)];
+                float4 a0 = S0[slot];
+                const float4 a1 = S1[slot], a2 = S2[slot], a3 = S3[slot];
+                uint32_t sb = __builtin_bit_cast(uint32_t, a0.w);
+                const uint32_t pixel = __builtin_bit_cast(uint32_t, a3.w);
+                f3 direct = mk3(a3.x, a3.y, a3.z);
+                f3 dir = mk3(a1.x, a1.y, a1.z);
+                alive = true;
+                if (sb & kEnded) {
+                    const float gainf = (sb & kGain) ? 1.2f : 1.0f;                 // :448-452
+                    const f3 result = scale3(tonemap3(direct), gainf);             // :362, :57-70
+                    a0.x += result.x; a0.y += result.y; a0.z += result.z;          // :457-458
+                    sb = (sb & kGain) | ((sb & 0xFFFFu) + 1u);                      // next frame, bounce 0
+                    direct = mk3(0.f, 0.f, 0.f);
+                    dir = mk3(a2.x, a2.y, a2.z);                                   // :293
+                    alive = (sb & 0xFFFFu) < spp_all;
+                }
+                if (alive) {
+                    const uint32_t sample = A.frame_index + (sb & 0xFFFFu);
+                    const uint32_t slot0 = ((sb >> 16) & 0x1FFFu) * slots;
+                    f3 dn;
+                    if (NOISE) { dn = add3(dir, rng_vec3(A, pixel, sample, slot0, -a2.w, a2.w)); }   // :118-119, :302
+                    else       { dn = add3(dir, mk3(0.f, 0.f, 0.f)); }
+                    float t;
+                    idx = closest_cam(campos, dn, t);                              // :304
+                    nrays++;
+                    if (idx < 0) {                                                 // :306-319
+                        const float clamped = __builtin_fminf(__builtin_fmaxf(dn.y, -1.f), 1.f);
+                        const float adjusted = (clamped + 1.f) * .5f;
+                        direct = add3(direct, color_lerp(mk3(.529f, .808f, .922f), mk3(.106f, .275f, .711f), adjusted));
+                        sb |= kEnded;
+                    }
+                    S1[slot] = make_float4(dn.x, dn.y, dn.z, t);
+                    S3[slot] = make_float4(direct.x, direct.y, direct.z, a3.w);
+                }
+                S0[slot] = make_float4(a0.x, a0.y, a0.z, __builtin_bit_cast(float, sb));
+            }
+            rhead += n;
+            __builtin_amdgcn_wave_barrier();
+            push(hitQ, htail, alive && idx >= 0, slot | ((uint32_t)idx << 8));
+            push(readyQ, rtail, alive && idx < 0, slot);
+        } else {
+            // ---- phase C: the hit side, :321-359 ----
+            uint32_t slot = 0;
+            if (lane < n) {
+                const uint32_t e = hitQ[(hhead + lane) & (QCAP - 1u)];
+                slot = e & 0xFFu;
+                const int idx = (int)(e >> 8);
+                const float4 a1 = S1[slot], a3 = S3[slot];
+                uint32_t sb = __builtin_bit_cast(uint32_t, S0[slot].w);
+                const uint32_t pixel = __builtin_bit_cast(uint32_t, a3.w);
+                const uint32_t sample = A.frame_index + (sb & 0xFFFFu);
+                uint32_t bounce = (sb >> 16) & 0x1FFFu;
+                const uint32_t slot0 = bounce * slots;
+                const f3 dn = mk3(a1.x, a1.y, a1.z);
+                f3 direct = mk3(a3.x, a3.y, a3.z);
+
+                const Hit hit = finish_hit(rec_gen, idx, campos, dn, a1.w);
+                const float4 m0 = l_mat0[idx];                   // diffuse rgb, albedo
+                const float2 m1 = l_mat1[idx];                   // metallic, roughness
+                const f3 diffuse = mk3(m0.x, m0.y, m0.z);
+                const float cos_theta = dot3(neg3(dn), hit.normal);   // :331-332
+                if (cos_theta >= 0.0f) {                         // :334
+                    f3 indirect = mk3(0.f, 0.f, 0.f);
+                    if (m0.w > 0.0f) {                           // :337
+                        if (pathtrace) {                         // :187
+                            for (uint32_t p = 0; p < A.paths; p++) {   // :192
+                                f3 d = normalize3(rng_vec3(A, pixel, sample, slot0 + 2u + p, -1.0f, 1.0f));  // :194
+                                if (dot3(d, hit.normal) < 0.0f) { d = neg3(d); }   // :197-200
+                                const f3 nd = add3(hit.normal, d);     // :202
+                                float tc;
+                                const int ci = closest_gen(hit.pos, nd, tc);   // :204
+                                nrays++;
+                                if (ci >= 0) {                   // :206-209
+                                    const float4 cm = l_mat0[ci];
+                                    indirect = add3(indirect, mk3(cm.x, cm.y, cm.z));
+                                }
+                            }
+                        }
+                        indirect = scale3(indirect, A.inv_samples);    // :212-213
+                        indirect = scale3(indirect, m0.w);       // :340
+                    }
+                    const float value = (cos_theta + 1.f) * .5f; // :343
+                    const float scalar = value * (1.f - m1.x);   // :345
+                    const f3 capture = color_lerp(diffuse, indirect, 1.f - scalar);   // :346
+                    direct = fma3(capture, scalar * .8f, direct);    // :347-349
+                }
+                bounce++;
+                const bool path_ends = (m1.x == 0.0f) || (bounce == A.bounces);   // :353-357, :300
+                if (!path_ends) {
+                    f3 nrm = hit.normal;
+                    if (NOISE) {
+                        const float gain = .2f * m1.y;           // :225
+                        nrm = add3(nrm, rng_vec3(A, pixel, sample, slot0 + 1u, -gain, gain));   // :226-227
+                    } else {
+                        nrm = add3(nrm, mk3(0.f, 0.f, 0.f));
+                    }
+                    const float k2 = 2.0f * dot3(dn, nrm);       // fx::reflect, :229
+                    const f3 dir = fma3(nrm, -k2, dn);           // :359
+                    S1[slot] = make_float4(dir.x, dir.y, dir.z, 0.f);
+                    sb += 1u << 16;
+                } else {
+                    sb |= kEnded;
+                }
+                S3[slot] = make_float4(direct.x, direct.y, direct.z, a3.w);
+                S0[slot].w = __builtin_bit_cast(float, sb);
+            }
+            hhead += n;
+            __builtin_amdgcn_wave_barrier();
+            push(readyQ, rtail, lane < n, slot);
+        }
+    }
+
+    // one write of the accumulation planes and the packed pixel per launch, as in render_kernel
+    __builtin_amdgcn_wave_barrier();
+    const auto E = kernarg_args();
+#pragma unroll 1
+    for (uint32_t j = 0; j < (uint32_t)(P / 64); j++) {
+        const uint32_t slot = j * 64u + lane;
+        const uint32_t x = tx * 32u + (slot & 31u), yl = ty * (uint32_t)(P / 32) + (slot >> 5);
+        if ((x < E->width) && (yl < E->rows)) {
+            const uint32_t local = yl * E->width + x;
+            const float4 a0 = S0[slot];
+            E->acc[0][local] = a0.x; E->acc[1][local] = a0.y; E->acc[2][local] = a0.z;
+            const float inv = 1.0f / E->frame_count_last;            // :460
+            int r = (int)((a0.x * inv) * 255.0f);                    // ::RGB, :44-55
+            int g = (int)((a0.y * inv) * 255.0f);
+            int b = (int)((a0.z * inv) * 255.0f);
+            const uint32_t flags = E->flags;
+            if (flags & FLAG_CLAMP_PACK) {
+                r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
+            }
+            const uint32_t px = pack_pixel(r, g, b, flags);
+            E->target[local] = px;                                   // :461
+            uint32_t* const mirror = E->target_mirror;
+            if (mirror) { mirror[E->mirror_is_frame ? frame_pixel(E, local) : local] = px; }
+        }
+    }
+    wave_add_u64(E->counters, nrays);
+}
+
+// ---------------------------------------------------------------------------------
 // Sphere-parallel variant for large scenes (n >= kSphereParallelMin).
 //
 // With thousands of spheres the scan is >99 % of the work and "one lane = one ray" wastes it
@@ -1713,6 +1963,17 @@ bool persistent_launch(uint32_t n_spheres, bool grid)
     return grid ? grid_wave_walk(n_spheres) : sphere_parallel_scene(n_spheres);
 }
 
+// Pixels per wave of the wavefront kernel (render_kernel_wf) for this launch, 0: the launch runs render_kernel.
+// Experiment switch: LUMA_WF = 128 / 192 / 256.
+static uint32_t wavefront_pixels(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit)
+{
+    static const int env = [] { const char* e = getenv("LUMA_WF"); return e ? atoi(e) : 0; }();
+    if (env != 128 && env != 192 && env != 256) { return 0; }
+    if (grid || from_hit || n_spheres < 1 || n_spheres > 8 || spp > 0xFFFFu) { return 0; }
+    (void)band_pixels;
+    return (uint32_t)env;
+}
+
 static uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid)
 {
     if (persistent_launch(n_spheres, grid)) { return 1; }
@@ -1748,6 +2009,7 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
     SplitPlan plan;
     plan.fine_row0 = rows;
     plan.split = choose_split((size_t)width * rows, spp, n_spheres, grid);
+    if (wavefront_pixels((size_t)width * rows, spp, n_spheres, grid, from_hit)) { plan.split = 1; return plan; }   // no lanes to split over, nothing parks
     const size_t per_pixel = (size_t)spp * 3u * sizeof(float);   // a slot per frame in each of three planes
     if (plan.split > 1) {
         plan.wanted_bytes = per_pixel * width * rows;
@@ -1951,6 +2213,20 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
                 fine = (int)args.fine;
 #undef LUMA_NF8
 #undef LUMA_NF
+            }
+        }
+        if (const uint32_t wf = wavefront_pixels((size_t)args.width * rows, args.spp, n, use_grid, from_hit)) {
+            if (args.split == 1 && !args.fine && args.bounces <= 0x1FFFu) {
+#define LUMA_WF(PX, N) { render_kernel_wf<PX, false, N>, render_kernel_wf<PX, true, N> }
+#define LUMA_WF8(PX) { LUMA_WF(PX, 1), LUMA_WF(PX, 2), LUMA_WF(PX, 3), LUMA_WF(PX, 4), LUMA_WF(PX, 5), LUMA_WF(PX, 6), LUMA_WF(PX, 7), LUMA_WF(PX, 8) }
+                static const kernel_t wf_table[3][8][2] = { LUMA_WF8(128), LUMA_WF8(192), LUMA_WF8(256) };
+#undef LUMA_WF8
+#undef LUMA_WF
+                const size_t wf_lds = (size_t)wf * 4 * sizeof(float4) + (wf <= 128 ? 128 : 256) * 2 * sizeof(uint16_t)
+                                    + 8 * (2 * sizeof(float4) + sizeof(float2));
+                const dim3 wf_grid(((args.width + 31u) / 32u) * ((rows + wf / 32u - 1u) / (wf / 32u)), 1);
+                hipLaunchKernelGGL(wf_table[wf / 64u - 2u][n - 1][noise], wf_grid, dim3(64), wf_lds, stream, args);
+                return hipGetLastError();
             }
         }
         if (use_grid) {                                          // records and materials stay in global memory
