@@ -917,21 +917,25 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
 // at a time, so its frames are still added in frame order (:457-458) and every path's arithmetic is the same
 // instruction sequence as in render_kernel: bit-identical frames.
 // ---------------------------------------------------------------------------------
+// LDS per pixel slot: U = (direction of the next step | after phase A the noised direction, t), V = (radiance of the
+// path so far, state word), W = (the pixel's accumulator, blur): 48 B.  The pixel's camera ray, read once per FRAME,
+// stays out of LDS: it comes from a table the wave fills at its start (RenderArgs::split_scratch: float4 per band
+// pixel).  (The accumulator read-modify-written in the accumulation planes themselves instead -- 36 B, 30 waves per
+// CU -- cost 0.67 of 2.01 ms in scattered L2 traffic: seven vector memory instructions per phase instead of one.)
 template <int P, bool NOISE, int NS>
 __global__ __launch_bounds__(64) void render_kernel_wf(const RenderArgs A)
 {
-    static_assert(P % 64 == 0 && P >= 128 && P <= 256, "slots are 8 bits of a queue entry; a wave's tile is 32 x (P / 32) pixels");
+    static_assert(P == 128, "a wave's tile is 32 x 4 pixels; slots are 7 bits of a queue entry");
     static_assert(NS >= 1 && NS <= 8, "the sphere index is 3 bits of a queue entry");
     extern __shared__ float4 lds_rec[];
-    float4* const S0 = lds_rec;                 // accumulator rgb, state word (frame, bounce, flags)
-    float4* const S1 = lds_rec + P;             // direction of the next step, or after phase A the noised direction, and t
-    float4* const S2 = lds_rec + 2 * P;         // the pixel's camera ray (camera.rays[index]), blur
-    float4* const S3 = lds_rec + 3 * P;         // radiance of the path so far (`direct`, :298), global pixel index
-    float4* const l_mat0 = lds_rec + 4 * P;     // [8]
+    float4* const U = lds_rec;
+    float4* const V = lds_rec + P;
+    float4* const l_mat0 = lds_rec + 2 * P;     // [8]
     float4* const l_gen = l_mat0 + 8;           // [8] general records (centre, radius), for the hit point's normal
     float2* const l_mat1 = reinterpret_cast<float2*>(l_gen + 8);           // [8]
-    constexpr uint32_t QCAP = P <= 128 ? 128u : 256u;                       // ring size: a power of two >= P
-    uint16_t* const readyQ = reinterpret_cast<uint16_t*>(l_mat1 + 8);      // [QCAP] ring
+    float4* const W = reinterpret_cast<float4*>(l_mat1 + 8);               // [P]
+    constexpr uint32_t QCAP = 128u;                                         // ring size: a power of two >= P
+    uint16_t* const readyQ = reinterpret_cast<uint16_t*>(W + P);           // [QCAP] ring
     uint16_t* const hitQ = readyQ + QCAP;                                   // [QCAP] ring
     constexpr uint32_t kEnded = 1u << 29, kGain = 1u << 30;                // state word: frame [0,16), bounce [16,29)
 
@@ -955,19 +959,29 @@ __global__ __launch_bounds__(64) void render_kernel_wf(const RenderArgs A)
         tail += (uint32_t)__builtin_popcountll(m);
     };
 
-    // the wave's tile: 32 pixels wide, P / 32 rows; slot = row in the tile * 32 + column
+    // the wave's tile: 32 pixels wide, 4 rows; slot = row in the tile * 32 + column
     const uint32_t tiles_x = (A.width + 31u) / 32u;
     const uint32_t ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const uint32_t x0 = tx * 32u, yl0 = ty * 4u;
+    // global index of the first pixel of each of the tile's rows (RNG, :399), wave-uniform
+    const uint32_t gp0 = global_row(A, min(yl0, A.rows - 1u)) * A.width + x0, gp1 = global_row(A, min(yl0 + 1u, A.rows - 1u)) * A.width + x0;
+    const uint32_t gp2 = global_row(A, min(yl0 + 2u, A.rows - 1u)) * A.width + x0, gp3 = global_row(A, min(yl0 + 3u, A.rows - 1u)) * A.width + x0;
+    const uint32_t local0 = yl0 * A.width + x0;
+    auto pixel_of = [&](uint32_t slot) {
+        const uint32_t r = slot >> 5;
+        return (r == 0u ? gp0 : r == 1u ? gp1 : r == 2u ? gp2 : gp3) + (slot & 31u);
+    };
+    auto local_of = [&](uint32_t slot) { return local0 + (slot >> 5) * A.width + (slot & 31u); };
+    float4* const raytab = reinterpret_cast<float4*>(A.split_scratch);
     const auto KA = kernarg_args();
     __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
     for (uint32_t j = 0; j < (uint32_t)(P / 64); j++) {
         const uint32_t slot = j * 64u + lane;
-        const uint32_t x = tx * 32u + (slot & 31u), yl = ty * (uint32_t)(P / 32) + (slot >> 5);
+        const uint32_t x = x0 + (slot & 31u), yl = yl0 + (slot >> 5);
         const bool live = (x < A.width) && (yl < A.rows);
         if (live) {
             const uint32_t y = global_row(A, yl);
-            const uint32_t local = yl * A.width + x;
             const f3 dir0 = camera_ray(KA, x, y);                // camera.rays[index], :413
             float t0;                                            // DOF pre-pass, :416-432
             const int h0 = closest_cam(campos, dir0, t0);
@@ -976,15 +990,16 @@ __global__ __launch_bounds__(64) void render_kernel_wf(const RenderArgs A)
             const float dd = depth - A.focus_depth;
             const float x2 = dd * dd, x4 = x2 * x2, x8 = x4 * x4, x10 = x8 * x2;
             const float focus = 1.0f - luma_expf(-x10);
-            const float blur = fma_(focus, 4.5f, 0.5f);
             const uint32_t sb = (A.show_depth && (focus < .5f)) ? kGain : 0u;
-            S0[slot] = make_float4(KA->acc[0][local], KA->acc[1][local], KA->acc[2][local], __builtin_bit_cast(float, sb));
-            S1[slot] = make_float4(dir0.x, dir0.y, dir0.z, 0.f);
-            S2[slot] = make_float4(dir0.x, dir0.y, dir0.z, blur);
-            S3[slot] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, y * A.width + x));
+            const uint32_t local = local_of(slot);
+            raytab[local] = make_float4(dir0.x, dir0.y, dir0.z, 0.f);
+            U[slot] = make_float4(dir0.x, dir0.y, dir0.z, 0.f);
+            V[slot] = make_float4(0.f, 0.f, 0.f, __builtin_bit_cast(float, sb));
+            W[slot] = make_float4(KA->acc[0][local], KA->acc[1][local], KA->acc[2][local], fma_(focus, 4.5f, 0.5f));   // :429-432
         }
         push(readyQ, rtail, live && spp_all > 0u, slot);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the table entries are written before any lane reads one
 
 #pragma unroll 1
     for (;;) {
@@ -1005,27 +1020,29 @@ __global__ __launch_bounds__(64) void render_kernel_wf(const RenderArgs A)
             bool alive = false;
             if (lane < n) {
                 slot = readyQ[(rhead + lane) & (QCAP - 1u)];
-                float4 a0 = S0[slot];
-                const float4 a1 = S1[slot], a2 = S2[slot], a3 = S3[slot];
-                uint32_t sb = __builtin_bit_cast(uint32_t, a0.w);
-                const uint32_t pixel = __builtin_bit_cast(uint32_t, a3.w);
-                f3 direct = mk3(a3.x, a3.y, a3.z);
-                f3 dir = mk3(a1.x, a1.y, a1.z);
+                const float4 u = U[slot], v = V[slot];
+                float4 w = W[slot];
+                const float blur = w.w;
+                uint32_t sb = __builtin_bit_cast(uint32_t, v.w);
+                f3 direct = mk3(v.x, v.y, v.z);
+                f3 dir = mk3(u.x, u.y, u.z);
                 alive = true;
                 if (sb & kEnded) {
+                    const float4 rt = raytab[local_of(slot)];
                     const float gainf = (sb & kGain) ? 1.2f : 1.0f;                 // :448-452
                     const f3 result = scale3(tonemap3(direct), gainf);             // :362, :57-70
-                    a0.x += result.x; a0.y += result.y; a0.z += result.z;          // :457-458
+                    w.x += result.x; w.y += result.y; w.z += result.z;             // :457-458
+                    W[slot] = w;
                     sb = (sb & kGain) | ((sb & 0xFFFFu) + 1u);                      // next frame, bounce 0
                     direct = mk3(0.f, 0.f, 0.f);
-                    dir = mk3(a2.x, a2.y, a2.z);                                   // :293
+                    dir = mk3(rt.x, rt.y, rt.z);                                   // :293
                     alive = (sb & 0xFFFFu) < spp_all;
                 }
                 if (alive) {
                     const uint32_t sample = A.frame_index + (sb & 0xFFFFu);
                     const uint32_t slot0 = ((sb >> 16) & 0x1FFFu) * slots;
                     f3 dn;
-                    if (NOISE) { dn = add3(dir, rng_vec3(A, pixel, sample, slot0, -a2.w, a2.w)); }   // :118-119, :302
+                    if (NOISE) { dn = add3(dir, rng_vec3(A, pixel_of(slot), sample, slot0, -blur, blur)); }   // :118-119, :302
                     else       { dn = add3(dir, mk3(0.f, 0.f, 0.f)); }
                     float t;
                     idx = closest_cam(campos, dn, t);                              // :304
@@ -1036,10 +1053,9 @@ __global__ __launch_bounds__(64) void render_kernel_wf(const RenderArgs A)
                         direct = add3(direct, color_lerp(mk3(.529f, .808f, .922f), mk3(.106f, .275f, .711f), adjusted));
                         sb |= kEnded;
                     }
-                    S1[slot] = make_float4(dn.x, dn.y, dn.z, t);
-                    S3[slot] = make_float4(direct.x, direct.y, direct.z, a3.w);
+                    U[slot] = make_float4(dn.x, dn.y, dn.z, t);
+                    V[slot] = make_float4(direct.x, direct.y, direct.z, __builtin_bit_cast(float, sb));
                 }
-                S0[slot] = make_float4(a0.x, a0.y, a0.z, __builtin_bit_cast(float, sb));
             }
             rhead += n;
             __builtin_amdgcn_wave_barrier();
@@ -1052,16 +1068,16 @@ __global__ __launch_bounds__(64) void render_kernel_wf(const RenderArgs A)
                 const uint32_t e = hitQ[(hhead + lane) & (QCAP - 1u)];
                 slot = e & 0xFFu;
                 const int idx = (int)(e >> 8);
-                const float4 a1 = S1[slot], a3 = S3[slot];
-                uint32_t sb = __builtin_bit_cast(uint32_t, S0[slot].w);
-                const uint32_t pixel = __builtin_bit_cast(uint32_t, a3.w);
+                const float4 u = U[slot], v = V[slot];
+                uint32_t sb = __builtin_bit_cast(uint32_t, v.w);
+                const uint32_t pixel = pixel_of(slot);
                 const uint32_t sample = A.frame_index + (sb & 0xFFFFu);
                 uint32_t bounce = (sb >> 16) & 0x1FFFu;
                 const uint32_t slot0 = bounce * slots;
-                const f3 dn = mk3(a1.x, a1.y, a1.z);
-                f3 direct = mk3(a3.x, a3.y, a3.z);
+                const f3 dn = mk3(u.x, u.y, u.z);
+                f3 direct = mk3(v.x, v.y, v.z);
 
-                const Hit hit = finish_hit(rec_gen, idx, campos, dn, a1.w);
+                const Hit hit = finish_hit(rec_gen, idx, campos, dn, u.w);
                 const float4 m0 = l_mat0[idx];                   // diffuse rgb, albedo
                 const float2 m1 = l_mat1[idx];                   // metallic, roughness
                 const f3 diffuse = mk3(m0.x, m0.y, m0.z);
@@ -1103,13 +1119,12 @@ __global__ __launch_bounds__(64) void render_kernel_wf(const RenderArgs A)
                     }
                     const float k2 = 2.0f * dot3(dn, nrm);       // fx::reflect, :229
                     const f3 dir = fma3(nrm, -k2, dn);           // :359
-                    S1[slot] = make_float4(dir.x, dir.y, dir.z, 0.f);
+                    U[slot] = make_float4(dir.x, dir.y, dir.z, 0.f);
                     sb += 1u << 16;
                 } else {
                     sb |= kEnded;
                 }
-                S3[slot] = make_float4(direct.x, direct.y, direct.z, a3.w);
-                S0[slot].w = __builtin_bit_cast(float, sb);
+                V[slot] = make_float4(direct.x, direct.y, direct.z, __builtin_bit_cast(float, sb));
             }
             hhead += n;
             __builtin_amdgcn_wave_barrier();
@@ -1123,15 +1138,16 @@ __global__ __launch_bounds__(64) void render_kernel_wf(const RenderArgs A)
 #pragma unroll 1
     for (uint32_t j = 0; j < (uint32_t)(P / 64); j++) {
         const uint32_t slot = j * 64u + lane;
-        const uint32_t x = tx * 32u + (slot & 31u), yl = ty * (uint32_t)(P / 32) + (slot >> 5);
+        const uint32_t x = x0 + (slot & 31u), yl = yl0 + (slot >> 5);
         if ((x < E->width) && (yl < E->rows)) {
             const uint32_t local = yl * E->width + x;
-            const float4 a0 = S0[slot];
-            E->acc[0][local] = a0.x; E->acc[1][local] = a0.y; E->acc[2][local] = a0.z;
+            const float4 w = W[slot];
+            const float ar = w.x, ag = w.y, ab = w.z;
+            E->acc[0][local] = ar; E->acc[1][local] = ag; E->acc[2][local] = ab;
             const float inv = 1.0f / E->frame_count_last;            // :460
-            int r = (int)((a0.x * inv) * 255.0f);                    // ::RGB, :44-55
-            int g = (int)((a0.y * inv) * 255.0f);
-            int b = (int)((a0.z * inv) * 255.0f);
+            int r = (int)((ar * inv) * 255.0f);                      // ::RGB, :44-55
+            int g = (int)((ag * inv) * 255.0f);
+            int b = (int)((ab * inv) * 255.0f);
             const uint32_t flags = E->flags;
             if (flags & FLAG_CLAMP_PACK) {
                 r = min(max(r, 0), 255); g = min(max(g, 0), 255); b = min(max(b, 0), 255);
@@ -1968,7 +1984,7 @@ bool persistent_launch(uint32_t n_spheres, bool grid)
 static uint32_t wavefront_pixels(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit)
 {
     static const int env = [] { const char* e = getenv("LUMA_WF"); return e ? atoi(e) : 0; }();
-    if (env != 128 && env != 192 && env != 256) { return 0; }
+    if (env != 128) { return 0; }
     if (grid || from_hit || n_spheres < 1 || n_spheres > 8 || spp > 0xFFFFu) { return 0; }
     (void)band_pixels;
     return (uint32_t)env;
@@ -2009,7 +2025,17 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
     SplitPlan plan;
     plan.fine_row0 = rows;
     plan.split = choose_split((size_t)width * rows, spp, n_spheres, grid);
-    if (wavefront_pixels((size_t)width * rows, spp, n_spheres, grid, from_hit)) { plan.split = 1; return plan; }   // no lanes to split over, nothing parks
+    if (wavefront_pixels((size_t)width * rows, spp, n_spheres, grid, from_hit)) {
+        // no lanes to split over, nothing parks: the scratch is the wave's table of camera rays, a float4 per band pixel
+        const size_t table = (size_t)width * rows * sizeof(float4);
+        if (table <= park_budget) {
+            plan.split = 1;
+            plan.wavefront = true;
+            plan.park_pixels = width * rows;
+            plan.park_bytes = table;
+            return plan;
+        }
+    }
     const size_t per_pixel = (size_t)spp * 3u * sizeof(float);   // a slot per frame in each of three planes
     if (plan.split > 1) {
         plan.wanted_bytes = per_pixel * width * rows;
@@ -2066,6 +2092,7 @@ void apply_plan(RenderArgs& args, const SplitPlan& plan, float* parking)
     args.park_row0 = plan.park_row0;
     args.park_pixels = plan.park_pixels;
     args.split_scratch = plan.park_bytes ? parking : nullptr;
+    args.wavefront = plan.wavefront ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------------------------
@@ -2215,19 +2242,14 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 #undef LUMA_NF
             }
         }
-        if (const uint32_t wf = wavefront_pixels((size_t)args.width * rows, args.spp, n, use_grid, from_hit)) {
-            if (args.split == 1 && !args.fine && args.bounces <= 0x1FFFu) {
-#define LUMA_WF(PX, N) { render_kernel_wf<PX, false, N>, render_kernel_wf<PX, true, N> }
-#define LUMA_WF8(PX) { LUMA_WF(PX, 1), LUMA_WF(PX, 2), LUMA_WF(PX, 3), LUMA_WF(PX, 4), LUMA_WF(PX, 5), LUMA_WF(PX, 6), LUMA_WF(PX, 7), LUMA_WF(PX, 8) }
-                static const kernel_t wf_table[3][8][2] = { LUMA_WF8(128), LUMA_WF8(192), LUMA_WF8(256) };
-#undef LUMA_WF8
+        if (args.wavefront) {
+#define LUMA_WF(N) { render_kernel_wf<128, false, N>, render_kernel_wf<128, true, N> }
+            static const kernel_t wf_table[8][2] = { LUMA_WF(1), LUMA_WF(2), LUMA_WF(3), LUMA_WF(4), LUMA_WF(5), LUMA_WF(6), LUMA_WF(7), LUMA_WF(8) };
 #undef LUMA_WF
-                const size_t wf_lds = (size_t)wf * 4 * sizeof(float4) + (wf <= 128 ? 128 : 256) * 2 * sizeof(uint16_t)
-                                    + 8 * (2 * sizeof(float4) + sizeof(float2));
-                const dim3 wf_grid(((args.width + 31u) / 32u) * ((rows + wf / 32u - 1u) / (wf / 32u)), 1);
-                hipLaunchKernelGGL(wf_table[wf / 64u - 2u][n - 1][noise], wf_grid, dim3(64), wf_lds, stream, args);
-                return hipGetLastError();
-            }
+            const size_t wf_lds = 128 * 3 * sizeof(float4) + 128 * 2 * sizeof(uint16_t) + 8 * (2 * sizeof(float4) + sizeof(float2));
+            const dim3 wf_grid(((args.width + 31u) / 32u) * ((rows + 3u) / 4u), 1);
+            hipLaunchKernelGGL(wf_table[n - 1][noise], wf_grid, dim3(64), wf_lds, stream, args);
+            return hipGetLastError();
         }
         if (use_grid) {                                          // records and materials stay in global memory
             // the grid's cell offsets go to LDS as 16-bit words when six workgroups' copies fit a CU
