@@ -62,11 +62,13 @@ def measured_traffic(workload):
     return None, None
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, deadline_s=420.0):
     """`bench.py --gpus N` from a plain shell: start the N rank processes ourselves.  This parent
     has made no GPU call and imported no torch; each rank is a fresh child (never an exec of a
     process that touched the GPU).  Rank 0's child prints the JSON line; the exit code is non-zero
-    if any rank fails, and the others are then stopped by their own PIDs."""
+    if any rank fails, and the others are then stopped by their own PIDs.  Ranks still running
+    `deadline_s` after the start (stuck in a rendezvous or a collective: the usual first-contact
+    failure) are stopped the same way, named on stderr, and the exit code is 124."""
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -78,6 +80,7 @@ def spawn_ranks(n, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
     rc = 0
     live = list(procs)
+    t0 = time.monotonic()
     while live:
         time.sleep(0.2)
         for p in list(live):
@@ -89,7 +92,102 @@ def spawn_ranks(n, argv):
                 rc = code
                 for q in live:                     # a rank died: the rest would wait in a collective forever
                     q.terminate()
+        if live and rc == 0 and time.monotonic() - t0 > deadline_s:
+            alive = sorted(procs.index(q) for q in live)
+            print(f"bench.py: ranks {alive} of {n} still running after {deadline_s:.0f} s "
+                  f"(exited cleanly: {sorted(set(range(n)) - set(alive))}); stopping them", file=sys.stderr, flush=True)
+            rc = 124
+            for q in live:
+                q.terminate()
+            t_kill = time.monotonic() + 10.0       # a rank stuck inside a GPU call may ignore SIGTERM
+            while any(q.poll() is None for q in live) and time.monotonic() < t_kill:
+                time.sleep(0.2)
+            for q in live:
+                if q.poll() is None:
+                    q.kill()
+            break
     return rc if rc >= 0 else 1
+
+
+def single_process(a, wl):
+    """`--single-process`: the product's own multi-GPU path (north_star: C++ host -> C-ABI -> RCCL).  ONE process,
+    one luma_group over devices 0..N-1; a step is one luma_hip_group_render_device call: every device renders its
+    band, one grouped ncclSend/ncclRecv exchange over the library's own communicator (ncclCommInitAll) puts the
+    frame together in the root GPU's memory (de-interleaved when striped), and the call returns when the frame is
+    complete -- nothing is hidden behind the next frame.  No torch in this process.  Prints one JSON line."""
+    from raytracer_amd import abi
+    n = a.gpus
+    seen = abi.device_count()
+    ids = list(range(n)) if seen >= n or not a.repeat_devices else [i % seen for i in range(n)]
+    if seen < n and not a.repeat_devices:
+        raise SystemExit(f"bench.py --single-process: --gpus {n} but {seen} device(s) visible (rehearsal on fewer: --repeat-devices)")
+    plan, members, ranks = abi.gather_plan(ids, WIDTH, HEIGHT)
+    params = abi.make_params(WIDTH, HEIGHT, spp=SPP, bounces=BOUNCES, paths=PATHS, samples=SAMPLES,
+                             mode=wl["mode"], flags=wl["flags"] | (abi.FLAG_GRID if a.grid else 0), seed=SEED)
+    with abi.Group(ids) as g:
+        g.set_scene(abi.synthetic_scene(wl["scene"], SEED) if wl["scene"] else abi.default_scene())
+        g.set_camera(abi.default_camera(WIDTH, HEIGHT))
+        g.set_frame(WIDTH, HEIGHT)
+        g.reserve(SPP)
+        g.frame_device()                            # the group's frame on the root: allocated before the timed region
+        for _ in range(max(a.warmup, 1)):           # the first call also builds the communicator
+            g.render_device(params, want_stats=False)
+        g.render_device(params, want_stats=True)    # drains the ray counters
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            g.render_device(params, want_stats=False)     # synchronous: frame complete on return
+        dt = time.perf_counter() - t0
+        st = g.render_device(params, want_stats=True)
+        rays_per_step = st.rays / (a.steps + 1)
+        tests_per_step = st.sphere_tests / (a.steps + 1)
+        n_frame = max(1, min(a.steps, 20))
+        t1 = time.perf_counter()
+        for _ in range(n_frame):
+            g.render_device(params, want_stats=False)
+            frame = g.read_frame()                  # + one D2H copy of the assembled frame
+        frame_ms = (time.perf_counter() - t1) / n_frame * 1e3
+        checksum = int(frame.astype("uint64").sum())
+    ms = dt / a.steps * 1e3
+    flop = FLOP_PER_TEST * tests_per_step + FLOP_PER_RAY * rays_per_step
+    achieved = flop / (st.kernel_ms * 1e-3) / 1e12 / len(ids)         # per GPU, over the slowest device's kernel
+    out = {
+        "metric": "Mrays/s", "value": rays_per_step * a.steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": n, "ranks": plan.n_ranks,
+        "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["name"] + f", seed 0x{SEED:08X}" + (", uniform grid (LUMA_FLAG_GRID)" if a.grid else ""),
+                   "parallelism": (f"single process, luma_hip_group_render_device over devices {ids}: {plan.n_ranks} RCCL rank(s) "
+                                   f"(ncclCommInitAll in the library), "
+                                   + (f"interleaved {plan.stripe_rows}-row stripes, grouped ncclSend/ncclRecv into a staging buffer + de-interleave on the root"
+                                      if plan.striped else "contiguous bands, grouped ncclSend/ncclRecv straight into the frame on the root")),
+                   "step": "render of every band + gather, synchronous: ms_per_step is a frame latency with the frame left in the root GPU's HBM"},
+        "frame_ms": frame_ms,
+        "frame_ms_definition": "wall of luma_hip_group_render_device + luma_hip_group_read_frame (one D2H copy of the assembled frame)",
+        "kernel_ms": st.kernel_ms, "gather_ms": st.gather_ms, "rays_per_step": rays_per_step, "frame_checksum": checksum,
+        "roofline": {"bound": "valu_fp32", "scope": "per GPU, slowest device's kernel", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                     "kernel": "luma::render_kernel", "flop_model": "17*sphere_tests + 64*rays (SURVEY 8d)"},
+    }
+    print(json.dumps(out), flush=True)
+
+
+def single_process_leg(a, timeout_s=150.0):
+    """Rank 0, after its own measurement: the same workload through the library's single-process path, in a fresh child
+    (no torch, no exec of this process), bounded in time.  Its JSON line, or what went wrong."""
+    argv = [sys.executable, os.path.abspath(__file__), "--gpus", str(a.gpus), "--single-process", "--workload", a.workload,
+            "--steps", str(min(a.steps, 30)), "--warmup", str(min(a.warmup, 3))] + (["--grid"] if a.grid else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                               "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    try:
+        r = subprocess.run(argv, env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"no result within {timeout_s:.0f} s (stopped)"}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"exit code {r.returncode}", "stderr_tail": r.stderr[-600:]}
+    d = json.loads(lines[-1])
+    keep = ("value", "unit", "ms_per_step", "frame_ms", "kernel_ms", "gather_ms", "ranks", "steps", "frame_checksum")
+    return dict({k: d[k] for k in keep}, parallelism=d["config"]["parallelism"], step=d["config"]["step"],
+                roofline_frac=d["roofline"]["frac"])
 
 
 def cpu_baseline(seconds_target=10.0, threads_all=None):
@@ -104,8 +202,9 @@ def cpu_baseline(seconds_target=10.0, threads_all=None):
     # in-tree library (oracle/Makefile, -O2 -march=x86-64-v3, portable) is the fallback.  The
     # arithmetic contract (-ffp-contract=off, explicit fmaf) is the same, so are the frames.
     flags = "-O2 -std=c99 -ffp-contract=off -fno-fast-math -march=x86-64-v3 (oracle/Makefile, prebuilt)"
+    tmp = tempfile.TemporaryDirectory(prefix="luma_oracle_")   # removed when this function returns (the library stays mapped)
     try:
-        native = os.path.join(tempfile.mkdtemp(prefix="luma_oracle_"), "libluma_oracle_native.so")
+        native = os.path.join(tmp.name, "libluma_oracle_native.so")
         opt = ["-O3", "-std=c99", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-march=native"]
         subprocess.check_call(["gcc"] + opt + ["-shared", "-o", native, os.path.join(ob.ORACLE_DIR, "luma_oracle.c"), "-lm"],
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120)
@@ -168,16 +267,31 @@ def main():
     ap.add_argument("--dist-backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks "
                          "(bands are gathered through host memory; not a measurement)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="one process, one luma_group over devices 0..N-1: the timed step is luma_hip_group_render_device "
+                         "(kernels + the library's own RCCL gather on the root); no torch, no rank processes")
+    ap.add_argument("--repeat-devices", action="store_true",
+                    help="with --single-process on a box with fewer GPUs than --gpus: reuse device ids (rehearsal, not a measurement)")
+    ap.add_argument("--no-single-process-leg", action="store_true",
+                    help="skip the `single_process` object of the line (rank 0 runs --single-process in a child after its own measurement)")
+    ap.add_argument("--rank-deadline", type=float, default=420.0,
+                    help="seconds after which the self-started ranks of --gpus N are stopped and named (exit 124)")
+    ap.add_argument("--selftest-hang-rank", type=int, default=-1, help="with --selftest-spawn: this rank never finishes")
     ap.add_argument("--selftest-spawn", action="store_true",
                     help="no GPU work: the ranks rendezvous (gloo), all-reduce their rank numbers, rank 0 prints "
                          "the sum; checks the launcher path of --gpus N on a box without GPUs")
     ap.add_argument("--selftest-fail-rank", type=int, default=-1, help="with --selftest-spawn: this rank exits 3 instead")
     a = ap.parse_args()
-    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))       # before any torch import or GPU call
     global WIDTH, HEIGHT, SPP, BOUNCES
     wl = WORKLOADS[a.workload]
     WIDTH, HEIGHT, SPP, BOUNCES = wl["w"], wl["h"], wl["spp"], wl["bounces"]
+    if a.single_process:
+        if int(os.environ.get("RANK", "0")) != 0:
+            return                                                 # under a rank launcher: one process does it all
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        return single_process(a, wl)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:], a.rank_deadline))   # before any torch import or GPU call
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL between processes needs dmabuf IPC on this driver
     import torch                                   # before abi.lib(): one shared HIP runtime
@@ -192,6 +306,8 @@ def main():
     if a.selftest_spawn:
         if rank == a.selftest_fail_rank:
             raise SystemExit(3)
+        if rank == a.selftest_hang_rank:
+            time.sleep(3600)
         dist.init_process_group("gloo")
         t = torch.tensor([rank], dtype=torch.int64)
         dist.all_reduce(t)
@@ -347,8 +463,11 @@ def main():
             "config": {"workload": wl["name"] + f", seed 0x{SEED:08X}" + (", uniform grid (LUMA_FLAG_GRID)" if a.grid else "")
                                    + (f", band {a.emulate_rank} of {a.emulate_world} only" if a.emulate_world else ""),
                        "parallelism": ("one GPU, whole frame" if world == 1 and not a.emulate_world
-                                       else f"{world} ranks, interleaved {stripe}-row stripes, RCCL gather to rank 0" if world > 1 and stripe
-                                       else f"{world} scanline band(s), RCCL gather to rank 0")},
+                                       else f"{world} rank processes, interleaved {stripe}-row stripes, torch.distributed (RCCL) gather to rank 0" if world > 1 and stripe
+                                       else f"{world} scanline band(s), torch.distributed (RCCL) gather to rank 0"),
+                       "step": ("one luma_hip_render_device call, frame left in HBM" if world == 1 and not a.force_dist
+                                else "render of this rank's band + hand-over to the gather; the gather of frame i overlaps the render of frame i+1 "
+                                     "(two band buffers), so ms_per_step is a THROUGHPUT figure -- frame_ms is the latency of one frame")},
             # ms_per_step (and value) time the step with the frame left in HBM, as the bench contract
             # asks; frame_ms is the host-target frame: kernel + (gather) + D2H into page-locked memory
             "frame_ms": None if a.no_frame_leg else frame_ms,
@@ -362,7 +481,8 @@ def main():
             "reference_equivalent_mrays_per_s": (rays_per_step + (SPP - 1) * WIDTH * (HEIGHT if not a.emulate_world else (y1 - y0)))
                                                 * a.steps / dt / 1e6,
             "kernel_ms": kernel_ms,
-            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
+            "roofline": {"bound": "valu_fp32", "scope": ("one GPU" if world == 1 else "per GPU: rank 0's launch over the slowest rank's kernel time"),
+                         "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_VALU_TFLOPS,
                          "peak_measured": PEAK_FP32_VALU_MEASURED_TFLOPS, "peak_measured_source": PEAK_MEASURED_SOURCE,
                          "frac_of_measured": achieved / PEAK_FP32_VALU_MEASURED_TFLOPS,
@@ -373,11 +493,16 @@ def main():
         }
         if not a.no_cpu_baseline and world == 1 and a.workload == "config3" and not a.emulate_world:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
 
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        if not a.no_single_process_leg and not a.emulate_world and not rehearsal and not a.force_dist:
+            # the product's own multi-GPU path beside the rank processes' figure: same frame, same devices, through
+            # luma_hip_group_render_device; the other ranks have let go of their GPUs' contexts by now
+            out["single_process"] = single_process_leg(a)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

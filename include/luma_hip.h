@@ -165,8 +165,10 @@ int luma_hip_render(luma_ctx* ctx, const luma_params* params, uint32_t* target_h
 int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* target_dev,
                            void* stream, luma_stats* stats);
 
-/* luma_hip_render_device for callers that cannot allocate device memory (code under HIP graph
- * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+/* luma_hip_render_device for callers that cannot allocate device memory (tight serving loops, harnesses
+ * that forbid hipMalloc, code that runs next to a HIP graph capture).  No counterpart in the reference.
+ * The call itself is not one to capture: frame numbers and 1/frame_count are launch arguments, a replay would add
+ * the same frames again; on a capturing stream it returns LUMA_E_STATE.
  * Same inputs, same frame and same accumulation planes as luma_hip_render_device, bit for bit, but
  * the scratch of its kernels (ray counters, the tile counter of large scenes, the planes in which
  * small bands park frames that several lanes of one pixel rendered) lies in a static device array of
@@ -179,8 +181,9 @@ int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* t
  * array): render the frames in several calls of fewer spp, which accumulates to the same bits.  LUMA_FLAG_GRID is rejected (LUMA_E_ARG): its tables are allocated
  * on first use and its kernels spill registers, which makes the HIP runtime set up memory of its
  * own at dispatch; the kernels behind every other flag use no private memory.  All calls
- * on one GPU share the array, from any context: two such calls that overlap in time on one GPU race;
- * keep them on one stream or order them yourself.  luma_hip_set_scene / _set_camera / _set_frame
+ * on one GPU share the array, from any context: the library orders them with one event per GPU (a call waits for
+ * the previous such call on that GPU, whatever its context or stream, at the cost of one stream-wait); calls made
+ * from several host threads at once still race and must be ordered by the caller.  luma_hip_set_scene / _set_camera / _set_frame
  * are set-up and do allocate; changing streams between calls on one context synchronises the device. */
 #define LUMA_HIP_NOALLOC_SCRATCH_BYTES (64u << 20)
 int luma_hip_render_device_noalloc(luma_ctx* ctx, const luma_params* params, uint32_t* target_dev,
@@ -329,6 +332,25 @@ typedef struct {
 } luma_split_plan;
 int luma_split_plan_describe(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_spheres, uint32_t flags,
                              uint64_t park_budget, luma_split_plan* plan);
+
+/* Host-only view of how a group cuts a frame and how luma_hip_group_render_device moves the bands to the root (no GPU
+ * work; for tests; no counterpart in the reference, which renders in one thread, Renderer.cpp:393): for n members with
+ * the given device ids (NULL: 0..n-1; ids may repeat) and a width x height frame.  The communicator
+ * (ncclCommInitAll) has one rank per DISTINCT device, in order of first appearance: rank_devices[n_ranks], rank 0 is the
+ * root.  Member i renders rows [row_begin, row_begin + rows) (contiguous bands), or with `striped` the stripes
+ * i, i + n, i + 2n, ... of stripe_rows rows each; its communicator rank comm_rank ncclSend's `pixels` uint32 and the root
+ * ncclRecv's them from that rank, in member order, at recv_offset pixels into the frame (contiguous) or into the staging
+ * buffer that the de-interleave kernel then puts in row order (striped).  members[n] and rank_devices[n] may be NULL. */
+typedef struct {
+    uint32_t n_members, n_ranks, striped, stripe_rows;
+} luma_gather_plan;
+typedef struct {
+    int32_t  device, comm_rank;
+    uint32_t row_begin, rows;
+    uint64_t pixels, recv_offset;
+} luma_gather_member;
+int luma_gather_plan_describe(int n, const int* device_ids, uint32_t width, uint32_t height, luma_gather_plan* plan,
+                              luma_gather_member* members, int* rank_devices);
 
 /* ---- diagnostics --------------------------------------------------------------- */
 const char* luma_hip_strerror(int code);

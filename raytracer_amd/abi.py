@@ -34,13 +34,22 @@ SYMBOLS = [
     "luma_hip_render_device_noalloc",
     "luma_hip_group_render_device", "luma_hip_group_frame_device", "luma_hip_group_read_frame",
     "luma_hip_reserve", "luma_hip_alloc_count", "luma_hip_group_reserve", "luma_view_grid_describe",
-    "luma_split_plan_describe",
+    "luma_split_plan_describe", "luma_gather_plan_describe",
 ]
 
 
 class SplitPlan(C.Structure):
     _fields_ = [("lanes", C.c_uint32), ("fine_lanes", C.c_uint32), ("fine_row0", C.c_uint32), ("park_row0", C.c_uint32),
                 ("park_bytes", C.c_uint64), ("refused", C.c_uint32)]
+
+
+class GatherPlan(C.Structure):
+    _fields_ = [("n_members", C.c_uint32), ("n_ranks", C.c_uint32), ("striped", C.c_uint32), ("stripe_rows", C.c_uint32)]
+
+
+class GatherMember(C.Structure):
+    _fields_ = [("device", C.c_int32), ("comm_rank", C.c_int32), ("row_begin", C.c_uint32), ("rows", C.c_uint32),
+                ("pixels", C.c_uint64), ("recv_offset", C.c_uint64)]
 
 
 class Sphere(C.Structure):
@@ -136,6 +145,8 @@ def lib():
         "luma_grid_describe": (C.c_int, [C.POINTER(Sphere), C.c_uint32, C.POINTER(GridInfo), u32p, u32p, u32p]),
         "luma_view_grid_describe": (C.c_int, [C.POINTER(Sphere), C.c_uint32, f32p, u32p, u32p, u32p, u32p, u32p, u32p]),
         "luma_split_plan_describe": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(SplitPlan)]),
+        "luma_gather_plan_describe": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.c_uint32, C.c_uint32, C.POINTER(GatherPlan),
+                                                C.POINTER(GatherMember), C.POINTER(C.c_int)]),
         "luma_hip_strerror": (C.c_char_p, [C.c_int]),
         "luma_hip_last_error": (C.c_char_p, []),
         "luma_hip_abi_version": (C.c_int, []),
@@ -248,6 +259,15 @@ def split_plan(width, rows, spp, n_spheres, flags=0, park_budget=2 << 30):
     plan = SplitPlan()
     check(lib().luma_split_plan_describe(width, rows, spp, n_spheres, flags, park_budget, C.byref(plan)), "luma_split_plan_describe")
     return plan
+
+
+def gather_plan(device_ids, width, height):
+    """luma_gather_plan_describe: (GatherPlan, [GatherMember], [device of each communicator rank]) -- host-only."""
+    n = len(device_ids)
+    ids = (C.c_int * max(n, 1))(*device_ids)
+    plan, members, ranks = GatherPlan(), (GatherMember * max(n, 1))(), (C.c_int * max(n, 1))()
+    check(lib().luma_gather_plan_describe(n, ids, width, height, C.byref(plan), members, ranks), "luma_gather_plan_describe")
+    return plan, list(members[:plan.n_members]), list(ranks[:plan.n_ranks])
 
 
 def device_count():

@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -61,6 +62,24 @@ private:
     int prev_;
 };
 
+// luma_hip_render_device_noalloc: every call on a GPU shares that GPU's static scratch array, whatever its context or
+// stream.  One event per device, created at luma_hip_create (set-up: the call itself must allocate nothing), orders
+// them: a call waits on it before it clears the counters and records it after its launch.
+std::mutex g_noalloc_lock;
+hipEvent_t g_noalloc_event[64] = {};
+hipError_t noalloc_event_for(int device, hipEvent_t* out)      // the device is current
+{
+    *out = nullptr;
+    if (device < 0 || device >= 64) { return hipErrorInvalidDevice; }
+    std::lock_guard<std::mutex> guard(g_noalloc_lock);
+    if (!g_noalloc_event[device]) {
+        hipError_t e = hipEventCreateWithFlags(&g_noalloc_event[device], hipEventDisableTiming);
+        if (e != hipSuccess) { g_noalloc_event[device] = nullptr; return e; }
+    }
+    *out = g_noalloc_event[device];
+    return hipSuccess;
+}
+
 template <typename T>
 void free_dev(T*& p)
 {
@@ -104,6 +123,7 @@ struct luma_ctx {
     bool last_split_refused = false;   //   than the 2 GiB cap on the parking planes allowed
 
     unsigned char* static_scratch = nullptr;   // this device's copy of luma_kernels.hip's `scratch` (render_device_noalloc)
+    hipEvent_t noalloc_event = nullptr;        // the device's "last use of the static scratch" event (shared, not owned)
 
     unsigned long long* d_counters = nullptr;  // rays traced since luma_hip_create, in kCounterSlots partial sums
     unsigned long long* h_counters = nullptr;  // pinned
@@ -438,8 +458,7 @@ int copy_band_to_frame(const luma_ctx* ctx, uint32_t* frame_host)
 // that says "band rendered", and on the root a staging buffer for interleaved-stripe bands plus the
 // group's own frame.  Built on first use, torn down with the group.
 struct GroupGather {
-    std::vector<int> devices;              // distinct devices, [0] = device of member 0 = the root
-    std::vector<int> rank_of_member;       // member -> index into devices / comms / streams
+    std::vector<int> devices;              // distinct devices, [0] = device of member 0 = the root (GatherPlan::rank_device)
     std::vector<ncclComm_t> comms;
     std::vector<hipStream_t> streams;      // the stream each communicator rank's sends / receives run on
     std::vector<hipEvent_t> rendered;      // per member, recorded on the member's stream
@@ -455,6 +474,7 @@ struct luma_group {
     std::vector<luma_ctx*> ctx;
     bool have_frame = false;
     bool striped = false;
+    luma::GatherPlan plan;                 // bands, communicator ranks and receive offsets (luma_host.h); valid with have_frame
     GroupGather gather;
 };
 
@@ -509,6 +529,7 @@ int luma_hip_create(luma_ctx** out, int device_id)
     void* scratch_ptr = nullptr;
     if ((e = luma::static_scratch_address(&scratch_ptr)) != hipSuccess) { return bail(e, "hipGetSymbolAddress(scratch)"); }
     ctx->static_scratch = static_cast<unsigned char*>(scratch_ptr);
+    if ((e = noalloc_event_for(device_id, &ctx->noalloc_event)) != hipSuccess) { return bail(e, "hipEventCreate(noalloc)"); }
     *out = ctx;
     return LUMA_OK;
 }
@@ -676,12 +697,22 @@ int luma_hip_reserve(luma_ctx* ctx, uint32_t max_spp)
     if (max_spp == 0) { return fail(LUMA_E_ARG, who, "max_spp must be >= 1"); }
     DeviceScope scope(ctx->device);
     if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
-    // the largest need over spp = 1 .. max_spp is at max_spp whenever frames are split at all
-    // (parking grows with spp: what max_spp needs covers every call of fewer; LUMA_FLAG_ORIGIN_FROM_HIT launches
-    //  have no fine class, so the other kind is the larger)
+    // Parking grows with spp, so what max_spp needs covers every call of fewer frames -- as long as the plan at max_spp
+    // is not REFUSED (wanted more than kMaxSplitBytes: it then runs one lane per pixel and parks little), in which case a
+    // later call of fewer spp that does fit wants more than max_spp did: the largest such call is planned as well.
+    // Every kind of launch is covered: with and without LUMA_FLAG_GRID (scenes of 320-511 spheres split only under the
+    // grid), with and without LUMA_FLAG_ORIGIN_FROM_HIT (no fine class).
     size_t need = 0;
-    for (int from_hit = 0; from_hit < 2; from_hit++) {
-        need = std::max(need, split_plan(ctx, max_spp, false, from_hit != 0, kMaxSplitBytes).park_bytes);
+    for (int grid = 0; grid < 2; grid++) {
+        for (int from_hit = 0; from_hit < 2; from_hit++) {
+            const luma::SplitPlan at_max = split_plan(ctx, max_spp, grid != 0, from_hit != 0, kMaxSplitBytes);
+            need = std::max(need, at_max.park_bytes);
+            if (at_max.refused) {
+                const size_t per_frame = ctx->band_pixels() * 3u * sizeof(float);
+                const uint32_t fits = static_cast<uint32_t>(std::min<size_t>(kMaxSplitBytes / per_frame, max_spp));
+                if (fits >= 1) { need = std::max(need, split_plan(ctx, fits, grid != 0, from_hit != 0, kMaxSplitBytes).park_bytes); }
+            }
+        }
     }
     if (need <= ctx->split_bytes) { return LUMA_OK; }
     return grow_split_planes(ctx, need);
@@ -767,6 +798,15 @@ int luma_hip_render_device_noalloc(luma_ctx* ctx, const luma_params* params, uin
     DeviceScope scope(ctx->device);
     if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    {
+        // not a call to capture into a HIP graph: the frame numbers and 1/frame_count are baked into the launch
+        // arguments, so a replay would add the same frames again
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &capturing) == hipSuccess && capturing != hipStreamCaptureStatusNone) {
+            return fail(LUMA_E_STATE, who, "stream is capturing: a captured call would replay the same frames; call it outside the capture");
+        }
+        (void)hipGetLastError();
+    }
     if (int rc = order_after_previous(ctx, s)) { return rc; }
     if (int rc = refresh_records(ctx, s)) { return rc; }          // a launch into memory luma_hip_set_scene allocated
 
@@ -778,8 +818,15 @@ int luma_hip_render_device_noalloc(luma_ctx* ctx, const luma_params* params, uin
     // every call on this GPU shares the array and finds the previous call's contents in it: the
     // counters (the tile counter must start at zero) are cleared; the parking planes need no
     // clearing, every slot that is read was written earlier in the same launch
-    LUMA_HIP_TRY(hipMemsetAsync(scratch, 0, kCounterAlloc, s));
-    LUMA_HIP_TRY(luma::launch_render(args, s));
+    {
+        // after the previous use of the array on this GPU, from whatever context or stream it came (concurrent
+        // host threads still have to order their calls themselves: the event is re-recorded by each)
+        std::lock_guard<std::mutex> guard(g_noalloc_lock);
+        LUMA_HIP_TRY(hipStreamWaitEvent(s, ctx->noalloc_event, 0));
+        LUMA_HIP_TRY(hipMemsetAsync(scratch, 0, kCounterAlloc, s));
+        LUMA_HIP_TRY(luma::launch_render(args, s));
+        LUMA_HIP_TRY(hipEventRecord(ctx->noalloc_event, s));
+    }
     ctx->frame_index += params->spp;
     ctx->last_stream = s;
     ctx->rendered = true;
@@ -865,7 +912,7 @@ void destroy_gather_comms(luma_group* g)
             if (G.ev_end) { (void)hipEventDestroy(G.ev_end); }
         }
     }
-    G.devices.clear(); G.rank_of_member.clear(); G.comms.clear(); G.streams.clear(); G.rendered.clear();
+    G.devices.clear(); G.comms.clear(); G.streams.clear(); G.rendered.clear();
     G.ev_begin = G.ev_end = nullptr;
     G.ready = false;
 }
@@ -927,17 +974,14 @@ int luma_hip_group_set_frame(luma_group* g, uint32_t width, uint32_t height)
     const uint32_t n = static_cast<uint32_t>(g->ctx.size());
     if (height < n) { return fail(LUMA_E_ARG, who, "fewer rows than devices: a band would be empty"); }
     g->have_frame = false;
-    constexpr uint32_t kStripeRows = 15;   // 1080, 2160 and 4320 are multiples of 15 * {1, 2, 4, 8}
-    const bool striped = n > 1 && height % (kStripeRows * n) == 0;
+    int ids[luma::kMaxGroupMembers];
+    for (uint32_t i = 0; i < n; i++) { ids[i] = g->ctx[i]->device; }
+    if (!luma::plan_gather(static_cast<int>(n), ids, width, height, &g->plan)) { return fail(LUMA_E_ARG, who, "zero width or height"); }
+    const bool striped = g->plan.striped != 0;
     for (uint32_t i = 0; i < n; i++) {
-        int rc;
-        if (striped) {
-            rc = luma_hip_set_frame_striped(g->ctx[i], width, height, kStripeRows, i, n);
-        } else {
-            const uint32_t y0 = static_cast<uint32_t>(static_cast<uint64_t>(i) * height / n);
-            const uint32_t y1 = static_cast<uint32_t>(static_cast<uint64_t>(i + 1) * height / n);
-            rc = luma_hip_set_frame(g->ctx[i], width, height, y0, y1);
-        }
+        const luma::GatherMember& m = g->plan.member[i];
+        const int rc = striped ? luma_hip_set_frame_striped(g->ctx[i], width, height, g->plan.stripe_rows, i, n)
+                               : luma_hip_set_frame(g->ctx[i], width, height, m.row_begin, m.row_begin + m.rows);
         if (rc) { return rc; }
     }
     g->have_frame = true;
@@ -1056,13 +1100,9 @@ int ensure_gather(luma_group* g)
     const luma::RcclApi* rccl = luma::rccl_api(&why);
     if (!rccl) { return fail(LUMA_E_RCCL, "RCCL is not available", why); }
     destroy_gather_comms(g);                                        // leftovers of a first use that failed
+    if (!g->have_frame) { return fail(LUMA_E_STATE, "luma_hip_group_render_device", "luma_hip_group_set_frame not called"); }
     try {
-        for (luma_ctx* c : g->ctx) {
-            size_t r = 0;
-            while (r < G.devices.size() && G.devices[r] != c->device) { r++; }
-            if (r == G.devices.size()) { G.devices.push_back(c->device); }
-            G.rank_of_member.push_back(static_cast<int>(r));
-        }
+        G.devices.assign(g->plan.rank_device, g->plan.rank_device + g->plan.n_ranks);
         G.comms.assign(G.devices.size(), nullptr);
         G.streams.assign(G.devices.size(), nullptr);
         G.rendered.assign(g->ctx.size(), nullptr);
@@ -1159,9 +1199,11 @@ int luma_hip_group_render_device(luma_group* g, const luma_params* params, uint3
             if (int rc = enqueue_render(c, params, c->d_target, c->stream, stats != nullptr)) { return rc; }
             LUMA_HIP_TRY(hipEventRecord(G.rendered[i], c->stream));
         }
-        // ... the exchange stream of each device waits for the bands rendered on that device ...
+        // ... the exchange stream of each device waits for the bands rendered on that device, the root's for
+        // every band: gather_ms then starts when the last band is done and times the exchange alone, not the
+        // skew between the devices' renders ...
         for (size_t i = 0; i < g->ctx.size(); i++) {
-            const int r = G.rank_of_member[i];
+            const int r = g->plan.member[i].comm_rank;
             DeviceScope scope(G.devices[r]);
             if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
             LUMA_HIP_TRY(hipStreamWaitEvent(G.streams[r], G.rendered[i], 0));
@@ -1169,6 +1211,9 @@ int luma_hip_group_render_device(luma_group* g, const luma_params* params, uint3
         {
             DeviceScope scope(G.devices[0]);
             if (!scope.ok()) { return fail(LUMA_E_HIP, who, "hipSetDevice failed"); }
+            for (size_t i = 0; i < g->ctx.size(); i++) {
+                if (g->plan.member[i].comm_rank != 0) { LUMA_HIP_TRY(hipStreamWaitEvent(G.streams[0], G.rendered[i], 0)); }
+            }
             LUMA_HIP_TRY(hipEventRecord(G.ev_begin, G.streams[0]));
         }
         // ... and ONE grouped exchange moves every band into the root: each member sends its band
@@ -1178,14 +1223,13 @@ int luma_hip_group_render_device(luma_group* g, const luma_params* params, uint3
         // staging buffer and one kernel puts the stripes in row order.  A member on the root's own
         // device goes the same way (a send to self inside the group is a local copy).
         LUMA_RCCL_TRY(rccl, rccl->GroupStart());
-        size_t staged = 0;
         int rc_group = LUMA_OK;
         for (size_t i = 0; i < g->ctx.size() && rc_group == LUMA_OK; i++) {
             luma_ctx* c = g->ctx[i];
-            const int r = G.rank_of_member[i];
-            const size_t count = c->band_pixels();
-            uint32_t* dst = g->striped ? G.staging + staged : frame_dev + static_cast<size_t>(c->row_begin) * width;
-            staged += count;
+            const luma::GatherMember& m = g->plan.member[i];              // the plan luma_gather_plan_describe shows
+            const int r = m.comm_rank;
+            const size_t count = static_cast<size_t>(m.pixels);
+            uint32_t* dst = (g->striped ? G.staging : frame_dev) + m.recv_offset;
             ncclResult_t e;
             {
                 DeviceScope scope(c->device);
@@ -1396,6 +1440,31 @@ int luma_split_plan_describe(uint32_t width, uint32_t rows, uint32_t spp, uint32
     plan->park_row0 = p.park_row0;
     plan->park_bytes = p.park_bytes;
     plan->refused = p.refused ? 1u : 0u;
+    return LUMA_OK;
+}
+
+int luma_gather_plan_describe(int n, const int* device_ids, uint32_t width, uint32_t height, luma_gather_plan* plan,
+                              luma_gather_member* members, int* rank_devices)
+{
+    if (!plan) { return fail(LUMA_E_ARG, "luma_gather_plan_describe", "null argument"); }
+    luma::GatherPlan P;
+    if (!luma::plan_gather(n, device_ids, width, height, &P)) {
+        return fail(LUMA_E_ARG, "luma_gather_plan_describe", "need 1 <= n <= 64 members, device ids >= 0, width > 0, height >= n");
+    }
+    plan->n_members = static_cast<uint32_t>(P.n_members);
+    plan->n_ranks = static_cast<uint32_t>(P.n_ranks);
+    plan->striped = P.striped;
+    plan->stripe_rows = P.stripe_rows;
+    for (int i = 0; members && i < P.n_members; i++) {
+        const luma::GatherMember& m = P.member[i];
+        members[i].device = m.device;
+        members[i].comm_rank = m.comm_rank;
+        members[i].row_begin = m.row_begin;
+        members[i].rows = m.rows;
+        members[i].pixels = m.pixels;
+        members[i].recv_offset = m.recv_offset;
+    }
+    for (int r = 0; rank_devices && r < P.n_ranks; r++) { rank_devices[r] = P.rank_device[r]; }
     return LUMA_OK;
 }
 

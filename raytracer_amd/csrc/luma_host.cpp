@@ -226,4 +226,37 @@ void scene_synthetic(luma_sphere* out, uint32_t n, uint64_t seed)
     }
 }
 
+bool plan_gather(int n, const int* device_ids, uint32_t width, uint32_t height, GatherPlan* out)
+{
+    if (!out || n < 1 || n > kMaxGroupMembers || width == 0 || height == 0 || height < (uint32_t)n) { return false; }
+    GatherPlan& P = *out;
+    P = GatherPlan{};
+    P.n_members = n;
+    constexpr uint32_t kStripeRows = 15;   // 1080, 2160 and 4320 are multiples of 15 * {1, 2, 4, 8}
+    P.striped = (n > 1 && height % (kStripeRows * (uint32_t)n) == 0) ? 1u : 0u;
+    P.stripe_rows = P.striped ? kStripeRows : 0u;
+    uint64_t staged = 0;
+    for (int i = 0; i < n; i++) {
+        const int dev = device_ids ? device_ids[i] : i;
+        if (dev < 0) { return false; }
+        int r = 0;
+        while (r < P.n_ranks && P.rank_device[r] != dev) { r++; }
+        if (r == P.n_ranks) { P.rank_device[P.n_ranks++] = dev; }
+        GatherMember& m = P.member[i];
+        m.device = dev;
+        m.comm_rank = r;
+        if (P.striped) {
+            m.row_begin = (uint32_t)i * kStripeRows;
+            m.rows = height / (uint32_t)n;
+        } else {
+            m.row_begin = (uint32_t)((uint64_t)i * height / (uint32_t)n);
+            m.rows = (uint32_t)((uint64_t)(i + 1) * height / (uint32_t)n) - m.row_begin;
+        }
+        m.pixels = (uint64_t)m.rows * width;
+        m.recv_offset = P.striped ? staged : (uint64_t)m.row_begin * width;
+        staged += m.pixels;
+    }
+    return true;
+}
+
 }  // namespace luma

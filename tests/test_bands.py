@@ -200,3 +200,11 @@ def test_bench_launcher_fails_when_a_rank_fails():
     r = _run_bench("--gpus", "3", "--selftest-spawn", "--selftest-fail-rank", "1", timeout=90)
     assert r.returncode == 3
     assert "spawn_selftest" not in r.stdout
+
+
+def test_bench_launcher_stops_ranks_that_hang():
+    """A rank stuck in a rendezvous or a collective (the usual first-contact failure on a new node) must not burn the
+    driver's whole time limit: after --rank-deadline seconds the parent stops the ranks, names them, exits 124."""
+    r = _run_bench("--gpus", "2", "--selftest-spawn", "--selftest-hang-rank", "1", "--rank-deadline", "10", timeout=90)
+    assert r.returncode == 124
+    assert "still running after 10 s" in r.stderr and "spawn_selftest" not in r.stdout

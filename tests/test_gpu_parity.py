@@ -652,6 +652,31 @@ def test_reserve_takes_allocation_out_of_the_render_call(abi):
         assert st.lanes_per_pixel == 1 and st.split_refused == 1 and ctx.alloc_count() == 0
 
 
+def test_reserve_covers_grid_launches_and_smaller_calls_after_a_refused_plan(abi):
+    """luma_hip_reserve plans every kind of launch the context can make, not only the linear scan at max_spp:
+    (a) 400 spheres run the sphere-parallel kernel (no parking) without LUMA_FLAG_GRID but the ray-per-lane kernel with
+    four lanes per pixel under it; (b) when max_spp itself is refused (parking past 2 GiB: one lane per pixel), a later
+    call of fewer spp that does fit wants MORE parking than max_spp did.  Neither may allocate in the render call."""
+    W, H = 1920, 1080
+    with abi.Context(0) as ctx:
+        ctx.set_scene(abi.synthetic_scene(400, SEED)); ctx.set_camera(abi.default_camera(W, H))
+        ctx.set_frame_striped(W, H, 15, 0, 8)
+        assert abi.split_plan(W, 135, 16, 400, flags=abi.FLAG_GRID).park_bytes > 0 == abi.split_plan(W, 135, 16, 400).park_bytes
+        ctx.reserve(16)
+        p = abi.make_params(W, H, spp=16, bounces=2, paths=1, samples=1, mode=1, flags=abi.FLAG_GRID, seed=SEED)
+        st = ctx.render_device(p, want_stats=True)
+        assert st.lanes_per_pixel == 4
+        assert ctx.alloc_count() == 6            # the grid's own tables (3 + 3, built on first use), no parking planes
+    W, H = 3840, 2160
+    with abi.Context(0) as ctx:
+        ctx.set_scene(abi.default_scene()); ctx.set_camera(abi.default_camera(W, H))
+        ctx.set_frame_striped(W, H, 15, 0, 8)
+        assert abi.split_plan(W, 270, 256, 5).refused == 1 and abi.split_plan(W, 270, 128, 5).refused == 0
+        ctx.reserve(256)
+        st = ctx.render_device(abi.make_params(W, H, spp=128, bounces=1, paths=1, samples=1, mode=0, flags=0, seed=SEED), want_stats=True)
+        assert st.lanes_per_pixel > 1 and st.split_refused == 0 and ctx.alloc_count() == 0
+
+
 # ---- bands gathered on the root GPU over RCCL (SURVEY 8e) -----------------------------
 
 @pytest.mark.parametrize("W,H,ids,scene_n", [
