@@ -25,6 +25,9 @@ static constexpr size_t kMaxSceneLdsBytes = 158 * 1024;
 // sphere-parallel scan (render_kernel_sp); smaller ones the ray-per-lane scan.
 static constexpr uint32_t kSphereParallelMin = 320;   // measured crossover (tools/scene_size_sweep.py)
 
+// Scenes of up to this many spheres run ray-per-lane instances with the sphere count as a template constant.
+static constexpr uint32_t kCompileTimeSpheresMax = 16;
+
 // FLAG_GRID: scenes with at least this many spheres walk the grid wave-cooperatively (wave_grid_walk).
 static constexpr uint32_t kGridWaveWalkMin = 512;
 
