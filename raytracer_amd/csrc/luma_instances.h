@@ -110,23 +110,4 @@
     X(render_kernel_sp<kTileW, 16, true, false, true, 2>) \
     X(render_kernel_sp<kTileW, 16, true, true, true, 2>)
 
-// wavefront form of the ray-per-lane kernel
-#define LUMA_LIST_WF(X) \
-    X(render_kernel_wf<128, false, 1>) \
-    X(render_kernel_wf<128, true, 1>) \
-    X(render_kernel_wf<128, false, 2>) \
-    X(render_kernel_wf<128, true, 2>) \
-    X(render_kernel_wf<128, false, 3>) \
-    X(render_kernel_wf<128, true, 3>) \
-    X(render_kernel_wf<128, false, 4>) \
-    X(render_kernel_wf<128, true, 4>) \
-    X(render_kernel_wf<128, false, 5>) \
-    X(render_kernel_wf<128, true, 5>) \
-    X(render_kernel_wf<128, false, 6>) \
-    X(render_kernel_wf<128, true, 6>) \
-    X(render_kernel_wf<128, false, 7>) \
-    X(render_kernel_wf<128, true, 7>) \
-    X(render_kernel_wf<128, false, 8>) \
-    X(render_kernel_wf<128, true, 8>)
-
-#define LUMA_LIST_ALL(X) LUMA_LIST_GENERAL(X) LUMA_LIST_GRID(X) LUMA_LIST_NS_1_4(X) LUMA_LIST_NS_5_8(X) LUMA_LIST_NS_9_12(X) LUMA_LIST_NS_13_16(X) LUMA_LIST_FINE_1_4(X) LUMA_LIST_FINE_5_8(X) LUMA_LIST_SP(X) LUMA_LIST_COOP(X) LUMA_LIST_WF(X)
+#define LUMA_LIST_ALL(X) LUMA_LIST_GENERAL(X) LUMA_LIST_GRID(X) LUMA_LIST_NS_1_4(X) LUMA_LIST_NS_5_8(X) LUMA_LIST_NS_9_12(X) LUMA_LIST_NS_13_16(X) LUMA_LIST_FINE_1_4(X) LUMA_LIST_FINE_5_8(X) LUMA_LIST_SP(X) LUMA_LIST_COOP(X)

@@ -92,7 +92,6 @@ struct RenderArgs {
     uint32_t  fine, fine_row0;
     uint32_t  coarse_wgs, coarse_gx, fine_gx;   // filled in by launch_render: workgroups of the coarse class, workgroups per row of each
     uint32_t  park_row0, park_pixels;           // the parking planes cover rows [park_row0, rows): park_pixels pixels each
-    uint32_t  wavefront;                        // 1: render_kernel_wf runs the launch; split_scratch is its table of camera rays (float4 per band pixel)
     uint32_t* tile_counter;        // sphere-parallel kernel: next wave tile, zeroed before every launch
     unsigned long long* counters;  // kCounterSlots x kCounterStride: [0] rays traced, [1] sphere tests; summed by the host
     GridArgs  grid;                // only read under FLAG_GRID
@@ -119,7 +118,6 @@ struct SplitPlan {
     uint32_t park_row0 = 0;        // rows [park_row0, rows) have lanes that park frames
     uint32_t park_pixels = 0;
     size_t   park_bytes = 0;       // spp x 3 planes x park_pixels floats; 0: nothing parks
-    bool     wavefront = false;    // the wavefront kernel runs the launch; park_bytes is its table of camera rays
     bool     refused = false;      // more than one lane per pixel was wanted, but its wanted_bytes of parking exceed the budget
     size_t   wanted_bytes = 0;
 };

@@ -13,7 +13,6 @@
 // to the reference's b = 2*dot, d = b*b - 4ac form because scaling by powers of two commutes
 // with rounding.
 #include "luma_device.hpp"
-#include "luma_device_wf.hpp"
 #include "luma_instances.h"
 
 namespace luma {
@@ -97,17 +96,6 @@ bool persistent_launch(uint32_t n_spheres, bool grid)
     return grid ? grid_wave_walk(n_spheres) : sphere_parallel_scene(n_spheres);
 }
 
-// Pixels per wave of the wavefront kernel (render_kernel_wf) for this launch, 0: the launch runs render_kernel.
-// Experiment switch: LUMA_WF = 128 / 192 / 256.
-static uint32_t wavefront_pixels(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit)
-{
-    static const int env = [] { const char* e = getenv("LUMA_WF"); return e ? atoi(e) : 0; }();
-    if (env != 128) { return 0; }
-    if (grid || from_hit || n_spheres < 1 || n_spheres > 8 || spp > 0xFFFFu) { return 0; }
-    (void)band_pixels;
-    return (uint32_t)env;
-}
-
 static uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid)
 {
     if (persistent_launch(n_spheres, grid)) { return 1; }
@@ -143,17 +131,6 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
     SplitPlan plan;
     plan.fine_row0 = rows;
     plan.split = choose_split((size_t)width * rows, spp, n_spheres, grid);
-    if (wavefront_pixels((size_t)width * rows, spp, n_spheres, grid, from_hit)) {
-        // no lanes to split over, nothing parks: the scratch is the wave's table of camera rays, a float4 per band pixel
-        const size_t table = (size_t)width * rows * sizeof(float4);
-        if (table <= park_budget) {
-            plan.split = 1;
-            plan.wavefront = true;
-            plan.park_pixels = width * rows;
-            plan.park_bytes = table;
-            return plan;
-        }
-    }
     const size_t per_pixel = (size_t)spp * 3u * sizeof(float);   // a slot per frame in each of three planes
     if (plan.split > 1) {
         plan.wanted_bytes = per_pixel * width * rows;
@@ -210,7 +187,6 @@ void apply_plan(RenderArgs& args, const SplitPlan& plan, float* parking)
     args.park_row0 = plan.park_row0;
     args.park_pixels = plan.park_pixels;
     args.split_scratch = plan.park_bytes ? parking : nullptr;
-    args.wavefront = plan.wavefront ? 1u : 0u;
 }
 
 // ---------------------------------------------------------------------------------
@@ -357,15 +333,6 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 #undef LUMA_NF8
 #undef LUMA_NF
             }
-        }
-        if (args.wavefront) {
-#define LUMA_WF(N) { render_kernel_wf<128, false, N>, render_kernel_wf<128, true, N> }
-            static const kernel_t wf_table[8][2] = { LUMA_WF(1), LUMA_WF(2), LUMA_WF(3), LUMA_WF(4), LUMA_WF(5), LUMA_WF(6), LUMA_WF(7), LUMA_WF(8) };
-#undef LUMA_WF
-            const size_t wf_lds = 128 * 3 * sizeof(float4) + 128 * 2 * sizeof(uint16_t) + 8 * (2 * sizeof(float4) + sizeof(float2));
-            const dim3 wf_grid(((args.width + 31u) / 32u) * ((rows + 3u) / 4u), 1);
-            hipLaunchKernelGGL(wf_table[n - 1][noise], wf_grid, dim3(64), wf_lds, stream, args);
-            return hipGetLastError();
         }
         if (use_grid) {                                          // records and materials stay in global memory
             // the grid's cell offsets go to LDS as 16-bit words when six workgroups' copies fit a CU
