@@ -40,7 +40,8 @@ LUMA_DEV float dot3(f3 a, f3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x
 // tools/exhaust_sqrt.hip compares both with hipcc's correctly rounded forms on every one of the
 // 1,610,612,736 binary32 inputs of the range, on MI355X: 0 mismatches (profiles/r02/exhaust_sqrt.txt;
 // outside the range they do differ, so other inputs take the compiler's forms).
-LUMA_DEV bool lean_range(float x) { return x >= 0x1p-96f && x < 0x1p96f; }
+// (one integer range test on the bits: 2^-96 <= x < 2^96; negative numbers, zero, subnormals, infinities and NaN fall outside)
+LUMA_DEV bool lean_range(float x) { return __builtin_bit_cast(uint32_t, x) - 0x0F800000u < 0x60000000u; }
 LUMA_DEV float sqrt_lean(float x)
 {
     const float y = __builtin_amdgcn_rsqf(x);
@@ -54,16 +55,18 @@ LUMA_DEV float rcp_lean(float s)
 }
 LUMA_DEV float sqrt_rn(float x)
 {
-    if (__builtin_expect(!lean_range(x), 0)) { return __builtin_sqrtf(x); }
-    return sqrt_lean(x);
+    // the short form for every lane, then the compiler's form over it for the lanes outside the range (none, in practice:
+    // a repair branch that is not taken costs less scalar work than an if / else around the two forms)
+    float s = sqrt_lean(x);
+    if (__builtin_expect(!lean_range(x), 0)) { s = __builtin_sqrtf(x); }
+    return s;
 }
 // fx::normalize: v * (1 / sqrt(dot(v,v))).  dot in [2^-96, 2^96) puts the length in [2^-48, 2^48).
 LUMA_DEV f3 normalize3(f3 a)
 {
     const float d = dot3(a, a);
-    float inv;
+    float inv = rcp_lean(sqrt_lean(d));
     if (__builtin_expect(!lean_range(d), 0)) { inv = 1.0f / __builtin_sqrtf(d); }
-    else                                     { inv = rcp_lean(sqrt_lean(d)); }
     return scale3(a, inv);
 }
 LUMA_DEV f3 fma3(f3 a, float s, f3 c) { return mk3(fma_(a.x, s, c.x), fma_(a.y, s, c.y), fma_(a.z, s, c.z)); }
@@ -227,18 +230,23 @@ LUMA_DEV int scan_spheres(RecPtr rec, uint32_t n, f3 origin, f3 dir, float& t_ou
     };
     // b >= 0 gives -b - sqrt(d) < 0, i.e. t <= 0 (:258 rejects it): such spheres skip the sqrt.
     auto candidate = [](float b, float d) { return d > 0.0f && b < 0.0f; };   // :253
+    // The common case is settled with selects, not branches (round 3: the divergent-if form of this block cost ~24 scalar
+    // and branch instructions per sphere for ~22 vector ones): `fast` says the numerator lies in [1e-20, 1e25] (one integer
+    // range test on its bits, which also says it is positive) and clearly below the best so far; what is positive and below
+    // the best but not `fast` (ties, extreme values, odd a) compares the quotients as the reference does, out of line.
     auto consider = [&](float b, float d, uint32_t i) {
         if (candidate(b, d)) {
             const float num = -b - sqrt_rn(d);                   // :255, numerator
-            if (num > 0.0f && num < best_num) {
-                bool take = true;
-                if (__builtin_expect(odd_a || !(num >= 1e-20f && num <= 1e25f) || !(num < best_num * 0.99999976f), 0)) {
-                    const float t = num / a;
-                    const float tb = (best < 0) ? FLT_MAX : best_num / a;
-                    take = (t > 0.0f) && (t < tb);               // :258, :266
-                }
-                if (take) { best_num = num; best = (int)i; }
+            const bool fast = (__builtin_bit_cast(uint32_t, num) - 0x1E3CE508u <= 0x69045951u - 0x1E3CE508u) & (num < best_num * 0.99999976f) & !odd_a;
+            const bool exact = (num > 0.0f) & (num < best_num) & !fast;
+            bool take = fast;
+            if (__builtin_expect(exact, 0)) {
+                const float t = num / a;
+                const float tb = (best < 0) ? FLT_MAX : best_num / a;
+                take = (t > 0.0f) && (t < tb);                   // :258, :266
             }
+            best_num = take ? num : best_num;
+            best = take ? (int)i : best;
         }
     };
 

@@ -1,7 +1,7 @@
-"""The headline kernels' register budgets, checked where the library is built (no GPU needed).  The one-class
-config #3 instance of the ray-per-lane kernel runs eight waves per SIMD only with at most 64 VGPRs and 80 SGPRs
-and no spills; one more live value in its loop costs a wave per SIMD and ~1.5 % (profiles/r02/
-ab_lazy_args.txt).  The two-class instance that renders the whole config #3 frame (FINE = 4) was measured at seven
+"""The headline kernels' register budgets, checked where the library is built (no GPU needed).  The config #3
+instances of the ray-per-lane kernel run seven waves per SIMD with at most 72 VGPRs and 96 SGPRs and no spills; an
+eighth wave (64 VGPRs) was worth ~1 % to the one-class instance (profiles/r02/ab_lazy_args.txt), one
+wave fewer costs 10 %.  The two-class instance that renders the whole config #3 frame (FINE = 4) was measured at seven
 waves per SIMD (72 VGPRs, 96 SGPRs) and must not spill: the no-allocation entry point launches it too.
 Compiles the kernel instance groups (luma_inst_*.hip) to assembly once (about a minute) and reads the kernels' metadata."""
 import os
@@ -49,13 +49,16 @@ def test_makefile_flags_are_the_ones_checked():
         assert flag in mk, flag
 
 
-def test_config3_kernel_keeps_eight_waves_per_simd(kernel_metadata):
-    # render_kernel<TILE_W=32, WAVES=4, SCENE_LDS_ALL, NOISE, !FROM_HIT, SPLIT=1, !GRID, NS=5, FINE=0>
+def test_config3_one_class_kernel_keeps_seven_waves_per_simd(kernel_metadata):
+    # render_kernel<TILE_W=32, WAVES=4, SCENE_LDS_ALL, NOISE, !FROM_HIT, SPLIT=1, !GRID, NS=5, FINE=0>: 64 VGPRs and eight
+    # waves until round 3, whose select-based candidate handling (-27 % scalar and branch instructions, -1.4 % time on the
+    # two-class instance that renders config #3) needs 65; eight waves were worth ~1 % to this instance, config #4 measured
+    # the same before and after (profiles/r03/ab_select_scan.txt)
     names = [n for n in kernel_metadata if re.search(r"render_kernelILi32ELi4ELi2ELb1ELb0ELi1ELb0ELi5ELi0E", n)]
     assert len(names) == 1, names
     k = kernel_metadata[names[0]]
-    assert k["vgpr_count"] <= 64, k
-    assert k["sgpr_count"] <= 80, k
+    assert k["vgpr_count"] <= 72, k
+    assert k["sgpr_count"] <= 96, k
     assert k["vgpr_spill_count"] == 0 and k["sgpr_spill_count"] == 0 and k["private_segment_fixed_size"] == 0, k
 
 
