@@ -176,7 +176,7 @@ int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* t
  * process end.  The call makes no hipMalloc / hipFree and calls no allocating routine; it returns
  * without waiting (no luma_stats: its rays are not added to the context's counters).
  * Limits: a call whose scratch need exceeds the array is rejected with LUMA_E_ARG and a message
- * giving both sizes (need = 32 KiB + spp * 12 B * band pixels for bands under 1.5 M pixels of scenes
+ * giving both sizes (need = 32 KiB + slots * 12 B * band pixels, slots = luma_split_plan.park_depth: about (L-1)/L of spp for L lanes per pixel, for bands under 1.5 M pixels of scenes
  * under 320 spheres, 32 KiB otherwise; larger bands park only their last rows, as many as fit the
  * array): render the frames in several calls of fewer spp, which accumulates to the same bits.  LUMA_FLAG_GRID is rejected (LUMA_E_ARG): its tables are allocated
  * on first use and its kernels spill registers, which makes the HIP runtime set up memory of its
@@ -324,11 +324,12 @@ int luma_view_grid_describe(const luma_sphere* spheres, uint32_t n, const float 
  * pixels, `spp` frames per call, a scene of `n_spheres`, with or without LUMA_FLAG_GRID, and at most
  * `park_budget` bytes for the planes in which lanes park frames.  lanes / fine_lanes: lanes per pixel in rows
  * [0, fine_row0) and [fine_row0, rows) (fine_lanes 0: one class, fine_row0 == rows); rows [park_row0, rows)
- * park frames, park_bytes in all; refused: more lanes were wanted than the budget allows. */
+ * park frames, park_bytes = park_depth * 12 B per such pixel; refused: more lanes were wanted than the budget allows. */
 typedef struct {
     uint32_t lanes, fine_lanes, fine_row0, park_row0;
     uint64_t park_bytes;
     uint32_t refused;
+    uint32_t park_depth;   /* slots per parked pixel: only frames claimed from the back are parked, frame spp-1-b in slot b */
 } luma_split_plan;
 int luma_split_plan_describe(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_spheres, uint32_t flags,
                              uint64_t park_budget, luma_split_plan* plan);

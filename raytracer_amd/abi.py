@@ -40,7 +40,7 @@ SYMBOLS = [
 
 class SplitPlan(C.Structure):
     _fields_ = [("lanes", C.c_uint32), ("fine_lanes", C.c_uint32), ("fine_row0", C.c_uint32), ("park_row0", C.c_uint32),
-                ("park_bytes", C.c_uint64), ("refused", C.c_uint32)]
+                ("park_bytes", C.c_uint64), ("refused", C.c_uint32), ("park_depth", C.c_uint32)]
 
 
 class GatherPlan(C.Structure):

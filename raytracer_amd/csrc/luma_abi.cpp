@@ -708,9 +708,12 @@ int luma_hip_reserve(luma_ctx* ctx, uint32_t max_spp)
             const luma::SplitPlan at_max = split_plan(ctx, max_spp, grid != 0, from_hit != 0, kMaxSplitBytes);
             need = std::max(need, at_max.park_bytes);
             if (at_max.refused) {
-                const size_t per_frame = ctx->band_pixels() * 3u * sizeof(float);
-                const uint32_t fits = static_cast<uint32_t>(std::min<size_t>(kMaxSplitBytes / per_frame, max_spp));
-                if (fits >= 1) { need = std::max(need, split_plan(ctx, fits, grid != 0, from_hit != 0, kMaxSplitBytes).park_bytes); }
+                uint32_t lo = 0, hi = max_spp;                   // largest spp below max_spp whose plan is not refused
+                while (hi - lo > 1) {
+                    const uint32_t mid = lo + (hi - lo) / 2;
+                    if (split_plan(ctx, mid, grid != 0, from_hit != 0, kMaxSplitBytes).refused) { hi = mid; } else { lo = mid; }
+                }
+                if (lo >= 1) { need = std::max(need, split_plan(ctx, lo, grid != 0, from_hit != 0, kMaxSplitBytes).park_bytes); }
             }
         }
     }
@@ -1439,6 +1442,7 @@ int luma_split_plan_describe(uint32_t width, uint32_t rows, uint32_t spp, uint32
     plan->fine_row0 = p.fine_row0;
     plan->park_row0 = p.park_row0;
     plan->park_bytes = p.park_bytes;
+    plan->park_depth = p.park_depth;
     plan->refused = p.refused ? 1u : 0u;
     return LUMA_OK;
 }

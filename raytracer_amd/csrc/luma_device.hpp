@@ -745,7 +745,8 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
             if (FINE && lone) { s++; return s < spp_all; }
             const uint32_t old = atomicAdd(&claim[cidx], k == 0 ? 1u : 0x10000u);
             const uint32_t f = old & 0xFFFFu, b = old >> 16;
-            if (f + b >= spp_all) { return false; }
+            // claims from the back stop at the last parking slot (refused ones still count up `b`, hence the min)
+            if (k == 0 ? f + min(b, A.park_depth) >= spp_all : (b >= A.park_depth) | (f + b >= spp_all)) { return false; }
             s = (k == 0) ? f : spp_all - 1u - b;
             return true;
         };
@@ -824,7 +825,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
                 if (!SPL || k == 0) {
                     acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
                 } else {
-                    float* park = KA->split_scratch + (size_t)s * 3u * npix + plocal;
+                    float* park = KA->split_scratch + (size_t)(spp_all - 1u - s) * 3u * npix + plocal;   // slot b of the claim
                     park[0] = result.x; park[npix] = result.y; park[2 * npix] = result.z;
                 }
                 if (!SPL) { s++; } else { have = next_frame(); }
@@ -853,14 +854,14 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
                 float pr[8], pg[8], pb[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float* park = E->split_scratch + (size_t)(f + j) * 3u * npix + plocal;
+                    const float* park = E->split_scratch + (size_t)(spp_all - 1u - (f + j)) * 3u * npix + plocal;
                     pr[j] = park[0]; pg[j] = park[npix]; pb[j] = park[2 * npix];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) { acc_r += pr[j]; acc_g += pg[j]; acc_b += pb[j]; }
             }
             for (; f < spp_all; f++) {
-                const float* park = E->split_scratch + (size_t)f * 3u * npix + plocal;
+                const float* park = E->split_scratch + (size_t)(spp_all - 1u - f) * 3u * npix + plocal;
                 acc_r += park[0]; acc_g += park[npix]; acc_b += park[2 * npix];
             }
         }

@@ -84,7 +84,7 @@ struct RenderArgs {
     uint32_t* target_mirror;    // the same pixels a second time, or null: page-locked host memory written by the kernel itself,
     uint32_t  mirror_is_frame;  // a band laid out like `target` (0) or the whole width x height frame (1: indexed by frame pixel)
     // frame splitting (ray-per-lane kernel): lanes per pixel (1, 2 or 4) and the planes where
-    // lanes 1.. park their frames: spp x 3 x band pixels floats (one slot per frame)
+    // lanes 1.. park their frames: park_depth x 3 x park_pixels floats
     uint32_t  split;
     float*    split_scratch;
     // two classes of workgroups in one launch (SplitPlan): rows [0, fine_row0) with `split` lanes per pixel, dispatched
@@ -92,6 +92,7 @@ struct RenderArgs {
     uint32_t  fine, fine_row0;
     uint32_t  coarse_wgs, coarse_gx, fine_gx;   // filled in by launch_render: workgroups of the coarse class, workgroups per row of each
     uint32_t  park_row0, park_pixels;           // the parking planes cover rows [park_row0, rows): park_pixels pixels each
+    uint32_t  park_depth;                       // slots per pixel: frame spp-1-b of a pixel is parked in slot b, b < park_depth
     uint32_t* tile_counter;        // sphere-parallel kernel: next wave tile, zeroed before every launch
     unsigned long long* counters;  // kCounterSlots x kCounterStride: [0] rays traced, [1] sphere tests; summed by the host
     GridArgs  grid;                // only read under FLAG_GRID
@@ -117,7 +118,8 @@ struct SplitPlan {
     uint32_t fine_row0 = 0;        // first band row of the fine class (== rows when none)
     uint32_t park_row0 = 0;        // rows [park_row0, rows) have lanes that park frames
     uint32_t park_pixels = 0;
-    size_t   park_bytes = 0;       // spp x 3 planes x park_pixels floats; 0: nothing parks
+    uint32_t park_depth = 0;       // slots per parked pixel (back claims only; see park_depth_for)
+    size_t   park_bytes = 0;       // park_depth x 3 planes x park_pixels floats; 0: nothing parks
     bool     refused = false;      // more than one lane per pixel was wanted, but its wanted_bytes of parking exceed the budget
     size_t   wanted_bytes = 0;
 };

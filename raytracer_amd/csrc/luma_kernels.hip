@@ -125,18 +125,38 @@ static bool fine_class_launch(uint32_t split, uint32_t spp, uint32_t n_spheres, 
     return split <= 4 && spp >= 8 && spp <= 0x7FFFu && !grid && !from_hit && n_spheres >= 1 && n_spheres <= 8;
 }
 
+// Slots of the parking planes.  Only the lanes that claim frames from the BACK park (lane 0 of a pixel adds its frames
+// directly), and they park frame spp-1-b in slot b: with L lanes per pixel they render (L-1)/L of the frames on average,
+// so the planes hold that share plus a margin (a quarter of lane 0's share, at least two frames), never more than
+// spp - 1; a back claim beyond the last slot is refused (render_kernel `next_frame`) and lane 0 renders what is left.
+// Round 2 kept a slot per frame: 64 instead of 52 at 64 spp x 4 lanes, 40 at 2 lanes, 58 at 8.
+static uint32_t park_depth_for(uint32_t spp, uint32_t lanes)
+{
+    if (lanes <= 1 || spp <= 1) { return 0; }
+    const uint32_t share = (uint32_t)(((uint64_t)spp * (lanes - 1) + lanes - 1) / lanes);
+#ifdef LUMA_SWEEP_FINE_PCT
+    if (const char* e = getenv("LUMA_PARK_MARGIN_DIV")) { return std::min(spp - 1u, share + std::max(2u, spp / ((uint32_t)atoi(e) * lanes))); }
+#endif
+    return std::min(spp - 1u, share + std::max(2u, spp / (4u * lanes)));
+}
+
 SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit,
                      size_t park_budget)
 {
     SplitPlan plan;
     plan.fine_row0 = rows;
     plan.split = choose_split((size_t)width * rows, spp, n_spheres, grid);
-    const size_t per_pixel = (size_t)spp * 3u * sizeof(float);   // a slot per frame in each of three planes
+    // the most lanes per pixel this launch may run (the fine class has twice the coarse one's, four at least)
+    const auto lanes_most = [&](uint32_t split) {
+        return fine_class_launch(split, spp, n_spheres, grid, from_hit) ? (split == 4 ? 8u : 4u) : split;
+    };
+    size_t per_pixel = (size_t)park_depth_for(spp, lanes_most(plan.split)) * 3u * sizeof(float);   // three planes of slots
     if (plan.split > 1) {
         plan.wanted_bytes = per_pixel * width * rows;
         if (plan.wanted_bytes > park_budget) {                   // one lane per pixel (a fine class may still fit)
             plan.split = 1;
             plan.refused = true;
+            per_pixel = (size_t)park_depth_for(spp, lanes_most(1)) * 3u * sizeof(float);
         }
     }
     if (fine_class_launch(plan.split, spp, n_spheres, grid, from_hit)) {
@@ -160,7 +180,7 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
 #endif
         size_t fine_rows = (size_t)((double)rows * share + 0.999);
         // with one lane per pixel above them only the fine rows park: as many of them as the budget holds
-        if (plan.split == 1) { fine_rows = std::min(fine_rows, park_budget / (per_pixel * width)); }
+        if (plan.split == 1) { fine_rows = std::min(fine_rows, park_budget / std::max<size_t>(per_pixel * width, 1)); }
         // whole coarse workgroups (4 rows each) above the class: rounded towards fewer fine rows where their parking is
         // what the budget limits, towards more where the whole band parks anyway
         const uint32_t above = rows - (uint32_t)std::min<size_t>(fine_rows, rows);
@@ -175,7 +195,11 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
     }
     plan.park_row0 = plan.split > 1 ? 0u : plan.fine_row0;
     plan.park_pixels = (rows - plan.park_row0) * width;
-    plan.park_bytes = (plan.split > 1 || plan.fine) ? per_pixel * plan.park_pixels : 0;
+    plan.park_depth = park_depth_for(spp, std::max(plan.split, plan.fine));
+#ifdef LUMA_SWEEP_FINE_PCT
+    if (getenv("LUMA_PARK_FULL")) { plan.park_depth = spp > 1 ? spp - 1 : 0; }   // sweep builds: a slot per frame, as in round 2
+#endif
+    plan.park_bytes = (plan.split > 1 || plan.fine) ? (size_t)plan.park_depth * 3u * sizeof(float) * plan.park_pixels : 0;
     return plan;
 }
 
@@ -186,6 +210,7 @@ void apply_plan(RenderArgs& args, const SplitPlan& plan, float* parking)
     args.fine_row0 = plan.fine_row0;
     args.park_row0 = plan.park_row0;
     args.park_pixels = plan.park_pixels;
+    args.park_depth = plan.park_depth;
     args.split_scratch = plan.park_bytes ? parking : nullptr;
 }
 

@@ -24,7 +24,9 @@ def test_config3_frame_and_its_bands(abi, rows, lanes, fine):
     fine_rows = rows - p.fine_row0
     share = {1: 0.10, 2: 0.10, 4: 0.05}[lanes]
     assert abs(fine_rows - share * rows) <= 4, (fine_rows, rows)
-    assert p.park_bytes == 64 * 12 * W * (rows - p.park_row0)
+    # only frames claimed from the back are parked: (L-1)/L of them plus a margin, for the most lanes per pixel of the launch
+    assert p.park_depth == {4: 52, 8: 58}[fine]
+    assert p.park_bytes == p.park_depth * 12 * W * (rows - p.park_row0)
 
 
 def test_no_fine_class_below_eight_frames_or_with_many_rounds(abi):
@@ -66,4 +68,6 @@ def test_awkward_row_counts(abi, rows):
         for width in (1, 31, 1920, 7680):
             p = abi.split_plan(width, rows, spp, 5)
             geometry_ok(p, rows)
-            assert p.park_bytes == (spp * 12 * width * (rows - p.park_row0) if (p.lanes > 1 or p.fine_lanes) else 0)
+            most = max(p.lanes, p.fine_lanes)
+            assert p.park_depth == (min(spp - 1, -(-spp * (most - 1) // most) + max(2, spp // (4 * most))) if most > 1 else 0)
+            assert p.park_bytes == (p.park_depth * 12 * width * (rows - p.park_row0) if most > 1 else 0)

@@ -123,7 +123,7 @@ def test_noalloc_rejects_what_does_not_fit(abi):
         ctx.set_camera(abi.default_camera(W, H))
         ctx.set_frame(W, H)
         kw = dict(bounces=5, paths=1, samples=1, mode=1, flags=0, seed=SEED)
-        need = 32 * 1024 + 64 * 12 * W * H
+        need = 32 * 1024 + abi.split_plan(W, H, 64, 5).park_depth * 12 * W * H     # slots for the frames claimed from the back
         assert need > abi.NOALLOC_SCRATCH_BYTES
         with pytest.raises(abi.LumaError) as e:
             ctx.render_device_noalloc(abi.make_params(W, H, spp=64, **kw))
