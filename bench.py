@@ -47,7 +47,7 @@ def measured_traffic(workload):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (FETCH_SIZE x2 for
     gfx950 + WRITE_SIZE), newest round first, with the commit the passes were taken at: a
     committed measurement, not a counter of this run.  (bytes, source) or (None, None)."""
-    for rnd in ("r02", "r01"):
+    for rnd in ("r03", "r02", "r01"):
         try:
             with open(os.path.join(ROOT, "profiles", rnd, "traffic.json")) as f:
                 doc = json.load(f)

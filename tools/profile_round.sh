@@ -8,7 +8,7 @@ OUT=$1; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 stats() {   # name, bench args...
   name=$1; shift
-  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$name" -- python3 bench.py --no-cpu-baseline --no-frame-leg "$@" > "$OUT/kt_$name.json" 2> "$OUT/kt_$name.err" || { echo "kernel-trace $name failed"; tail -3 "$OUT/kt_$name.err"; exit 1; }
+  timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$name" -- python3 bench.py --no-cpu-baseline --no-frame-leg --no-single-process-leg "$@" > "$OUT/kt_$name.json" 2> "$OUT/kt_$name.err" || { echo "kernel-trace $name failed"; tail -3 "$OUT/kt_$name.err"; exit 1; }
   f=$(find "$OUT/kt_$name" -name '*kernel_stats.csv' | head -1)
   [ -n "$f" ] && cp "$f" "$OUT/${name}_kernel_stats.csv"
   echo "== $name"; head -4 "$OUT/${name}_kernel_stats.csv"
