@@ -214,6 +214,7 @@ LUMA_DEV int scan_spheres(RecPtr rec, uint32_t n, f3 origin, f3 dir, float& t_ou
     const bool odd_a = !(a > 1e-12f && a < 1e12f);
     float best_num = __builtin_inff();
     int best = -1;
+    bool any_exact = false;                                      // some candidate of this scan took the exact path
 
     // b (half of :247) and d (quarter of :251) of one sphere
     auto test = [&](const float4 s, float& b, float& d) {
@@ -241,6 +242,7 @@ LUMA_DEV int scan_spheres(RecPtr rec, uint32_t n, f3 origin, f3 dir, float& t_ou
             const bool exact = (num > 0.0f) & (num < best_num) & !fast;
             bool take = fast;
             if (__builtin_expect(exact, 0)) {
+                any_exact = true;
                 const float t = num / a;
                 const float tb = (best < 0) ? FLT_MAX : best_num / a;
                 take = (t > 0.0f) && (t < tb);                   // :258, :266
@@ -288,7 +290,19 @@ LUMA_DEV int scan_spheres(RecPtr rec, uint32_t n, f3 origin, f3 dir, float& t_ou
         test(rec[i], b, d);
         consider(b, d, i);
     }
-    t_out = (best >= 0) ? best_num / a : FLT_MAX;
+    // The winner's quotient.  A winner that no candidate contested through the exact path has 1e-12 < a < 1e12 and
+    // 1e-20 <= num <= 1e25: quotient, reciprocal and residuals are normal, where the six-instruction division below gives
+    // the correctly rounded quotient for every pair of significands (tools/exhaust_div.hip: all 2^46 pairs,
+    // profiles/r02/exhaust_div.txt) instead of the compiler's eleven; anything else takes the compiler's.
+    float q;
+    {
+        const float y0 = __builtin_amdgcn_rcpf(a);
+        const float y = fma_(fma_(-a, y0, 1.0f), y0, y0);
+        const float q0 = best_num * y;
+        q = fma_(fma_(-a, q0, best_num), y, q0);
+    }
+    if (__builtin_expect(any_exact, 0)) { q = best_num / a; }
+    t_out = (best >= 0) ? q : FLT_MAX;
     return best;
 }
 
