@@ -277,9 +277,8 @@ LUMA_DEV int scan_spheres(RecPtr rec, uint32_t n, f3 origin, f3 dir, float& t_ou
             const float4 s0 = rec[i], s1 = rec[i + 1], s2 = rec[i + 2], s3 = rec[i + 3];
             float b0, d0, b1, d1, b2, d2, b3, d3;
             test(s0, b0, d0); test(s1, b1, d1); test(s2, b2, d2); test(s3, b3, d3);
-            // candidate(b,d) == (min(d,-b) > 0); the max over the four is a cheap superset test
-            const float any = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, -b0), __builtin_fminf(d1, -b1)),
-                                              __builtin_fmaxf(__builtin_fminf(d2, -b2), __builtin_fminf(d3, -b3)));
+            // the largest discriminant of the four is a cheap superset test for "some candidate" (see wave_scan_one)
+            const float any = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(d0, d1), d2), d3);
             if (any > 0.0f) {
                 consider(b0, d0, i); consider(b1, d1, i + 1); consider(b2, d2, i + 2); consider(b3, d3, i + 3);
             }
@@ -978,8 +977,9 @@ LUMA_DEV unsigned long long wave_scan_one(const float4* __restrict__ rec, uint32
         const float4 s2 = rec[base + 128 + lane], s3 = rec[base + 192 + lane];
         float b0, d0, b1, d1, b2, d2, b3, d3;
         test(s0, b0, d0); test(s1, b1, d1); test(s2, b2, d2); test(s3, b3, d3);
-        const float any = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, -b0), __builtin_fminf(d1, -b1)),
-                                          __builtin_fmaxf(__builtin_fminf(d2, -b2), __builtin_fminf(d3, -b3)));
+        // (a superset test on the discriminants alone: two v_max3 and a compare per four tests where min(d, -b) per test
+        //  cost eight; the few passes it lets through for spheres behind the ray find no candidate)
+        const float any = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(d0, d1), d2), d3);
         if (any > 0.0f) {
             consider(b0, d0, base + lane); consider(b1, d1, base + 64 + lane);
             consider(b2, d2, base + 128 + lane); consider(b3, d3, base + 192 + lane);
@@ -1048,8 +1048,7 @@ LUMA_DEV void wave_scan_many(const float4* __restrict__ rec, uint32_t n_pad, uin
             if (R == 1 || (uint32_t)r < cnt) {                             // wave-uniform
                 float b0, d0, b1, d1, b2, d2, b3, d3;
                 test(r, s0, b0, d0); test(r, s1, b1, d1); test(r, s2, b2, d2); test(r, s3, b3, d3);
-                const float any = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(d0, -b0), __builtin_fminf(d1, -b1)),
-                                                  __builtin_fmaxf(__builtin_fminf(d2, -b2), __builtin_fminf(d3, -b3)));
+                const float any = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(d0, d1), d2), d3);   // (as in wave_scan_one)
                 if (any > 0.0f) {
                     consider(r, b0, d0, base + lane); consider(r, b1, d1, base + 64 + lane);
                     consider(r, b2, d2, base + 128 + lane); consider(r, b3, d3, base + 192 + lane);

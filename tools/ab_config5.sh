@@ -5,7 +5,7 @@ pp='import json,sys; d=json.loads(sys.stdin.read()); print(round(d["kernel_ms"],
 for rep in 1 2; do
 for lib in "$@"; do
   echo -n "$lib: "
-  LUMA_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload config5 --emulate-world 8 --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "$pp"
+  LUMA_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload config5 --emulate-world 8 --steps 3 --warmup 1 --no-cpu-baseline --no-single-process-leg 2>/dev/null | python -c "$pp"
   echo
 done
 done

@@ -6,8 +6,8 @@ pp='import json,sys; d=json.loads(sys.stdin.read()); print(round(d["kernel_ms"],
 for rep in 1 2; do
 for lib in "$@"; do
   echo -n "$lib: config5 band linear / grid: "
-  LUMA_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload config5 --emulate-world 8 --steps 3 --warmup 1 --no-cpu-baseline --no-frame-leg 2>/dev/null | python -c "$pp"
-  LUMA_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload config5 --emulate-world 8 --grid --steps 10 --warmup 2 --no-cpu-baseline --no-frame-leg 2>/dev/null | python -c "$pp"
+  LUMA_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload config5 --emulate-world 8 --steps 3 --warmup 1 --no-cpu-baseline --no-frame-leg --no-single-process-leg 2>/dev/null | python -c "$pp"
+  LUMA_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload config5 --emulate-world 8 --grid --steps 10 --warmup 2 --no-cpu-baseline --no-frame-leg --no-single-process-leg 2>/dev/null | python -c "$pp"
   echo -n " 640x360 x16 spp, 2000 spheres linear / grid, 30000 grid: "
   LUMA_HIP_LIB=$PWD/$lib timeout -k 10 200 python tools/small_frame_big_scene.py
   echo

@@ -5,7 +5,7 @@ export LUMA_AB=1   # abi.py honours LUMA_HIP_LIB only with this
 pp='import json,sys; d=json.loads(sys.stdin.read()); print(round(d["kernel_ms"],3), end=" ")'
 for lib in "$@"; do
   echo -n "$lib: config5 band: "
-  LUMA_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload config5 --emulate-world 8 --steps 3 --warmup 1 --no-cpu-baseline --no-frame-leg 2>/dev/null | python -c "$pp"
+  LUMA_HIP_LIB=$PWD/$lib timeout -k 10 200 python bench.py --workload config5 --emulate-world 8 --steps 3 --warmup 1 --no-cpu-baseline --no-frame-leg --no-single-process-leg 2>/dev/null | python -c "$pp"
   echo -n " scenes: "
   LUMA_HIP_LIB=$PWD/$lib timeout -k 10 200 python - <<'PY'
 import sys; sys.path.insert(0, '.')
