@@ -588,8 +588,18 @@ extern "C" int luma_dbg_timeline_copy(void* host, size_t bytes)
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dbg_timeline), bytes);
 }
 #endif
+#ifndef LUMA_DEFER
+#define LUMA_DEFER 1
+#endif
+#ifndef LUMA_DEFER_NUM
+#define LUMA_DEFER_NUM 1u
+#define LUMA_DEFER_DEN 2u
+#endif
+#ifndef LUMA_DEFER_WAVES
+#define LUMA_DEFER_WAVES 7
+#endif
 template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT, bool GRID, int NS = 0, int FINE = 0>
-__global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const RenderArgs A)
+__global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUMA_DEFER_WAVES : 1) void render_kernel(const RenderArgs A)
 {
     // [0,n): camera-origin records; [n,2n): general records; then mat0[n] (float4), mat1[n] (float2)
     extern __shared__ float4 lds_rec[];
@@ -628,6 +638,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
 
     // lane -> pixel inside the wave tile; wave -> (frame block k, tile inside the workgroup)
     constexpr bool SPL = SPLIT > 1 || FINE > 0;                  // frames of a pixel are claimed through LDS
+    constexpr bool DEFER = LUMA_DEFER && NS > 0 && !GRID;       // hits wait for company (see the loop skeletons below)
     constexpr int TILE_H = 64 / TILE_W;
     constexpr int WPK = WAVES / SPLIT;                           // waves per frame block
     constexpr int WGX = wg_waves_x(WPK), WGY = WPK / WGX;
@@ -765,88 +776,125 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : 1) void render_kernel(const 
         };
         bool have = !SPL ? true : next_frame();                  // one lane per pixel everywhere: plainly frames 0 .. spp-1
 
-        while (!SPL ? s < spp_all : have) {
+        // One trip of the flat (sample, bounce) loop, in the four pieces the two loop skeletons below arrange:
+        // the ray of the trip and its scan; a miss; a hit (the long piece: the indirect ray with its scan, shading,
+        // the reflected direction); the end of a path.
+        // (`dir` is the direction the trip starts from until its scan and the jittered one, `dn` of the reference's loop,
+        //  from there on: one set of registers, also while a hit waits in the second skeleton)
+        float t = 0.f;
+        int idx = -1;
+        bool path_ends = false;
+        auto trip_scan = [&]() {
             const uint32_t sample = A.frame_index + s;
-            f3 dn = dir;
-            if (NOISE) { dn = add3(dir, rng_vec3(A, pixel, sample, slot, -blur, blur)); }   // :118-119, :302
-            else       { dn = add3(dir, mk3(0.f, 0.f, 0.f)); }
-
-            float t;
-            int idx;
-            if (FROM_HIT && bounce > 0) { idx = closest_gen(origin, dn, t); }
-            else                        { idx = closest_cam(origin, dn, t); }   // :304
+            if (NOISE) { dir = add3(dir, rng_vec3(A, pixel, sample, slot, -blur, blur)); }   // :118-119, :302
+            else       { dir = add3(dir, mk3(0.f, 0.f, 0.f)); }
+            if (FROM_HIT && bounce > 0) { idx = closest_gen(origin, dir, t); }
+            else                        { idx = closest_cam(origin, dir, t); }   // :304
             nrays++;
+        };
+        auto trip_miss = [&]() {                                 // :306-319
+            const float clamped = __builtin_fminf(__builtin_fmaxf(dir.y, -1.f), 1.f);
+            const float adjusted = (clamped + 1.f) * .5f;
+            direct = add3(direct, color_lerp(mk3(.529f, .808f, .922f), mk3(.106f, .275f, .711f), adjusted));
+            path_ends = true;
+        };
+        auto trip_hit = [&]() {
+            const uint32_t sample = A.frame_index + s;
+            const Hit hit = finish_hit(rec_gen, idx, origin, dir, t);
+            const float4 m0 = mat0[idx];                       // diffuse rgb, albedo
+            const float2 m1 = mat1[idx];                       // metallic, roughness
+            const f3 diffuse = mk3(m0.x, m0.y, m0.z);
+            const float cos_theta = dot3(neg3(dir), hit.normal);       // :331-332
 
-            bool path_ends;
-            if (idx < 0) {                                       // :306-319
-                const float clamped = __builtin_fminf(__builtin_fmaxf(dn.y, -1.f), 1.f);
-                const float adjusted = (clamped + 1.f) * .5f;
-                direct = add3(direct, color_lerp(mk3(.529f, .808f, .922f), mk3(.106f, .275f, .711f), adjusted));
-                path_ends = true;
-            } else {
-                const Hit hit = finish_hit(rec_gen, idx, origin, dn, t);
-                const float4 m0 = mat0[idx];                   // diffuse rgb, albedo
-                const float2 m1 = mat1[idx];                   // metallic, roughness
-                const f3 diffuse = mk3(m0.x, m0.y, m0.z);
-                const float cos_theta = dot3(neg3(dn), hit.normal);   // :331-332
-
-                if (cos_theta >= 0.0f) {                         // :334
-                    f3 indirect = mk3(0.f, 0.f, 0.f);
-                    if (m0.w > 0.0f) {                           // :337
-                        if (pathtrace) {                         // :187
-                            for (uint32_t p = 0; p < A.paths; p++) {   // :192
-                                f3 d = normalize3(rng_vec3(A, pixel, sample, slot + 2u + p, -1.0f, 1.0f));  // :194
-                                if (dot3(d, hit.normal) < 0.0f) { d = neg3(d); }   // :197-200
-                                const f3 nd = add3(hit.normal, d);     // :202
-                                float tc;
-                                const int ci = closest_gen(hit.pos, nd, tc);   // :204
-                                nrays++;
-                                if (ci >= 0) {                   // :206-209
-                                    const float4 cm = mat0[ci];
-                                    indirect = add3(indirect, mk3(cm.x, cm.y, cm.z));
-                                }
+            if (cos_theta >= 0.0f) {                             // :334
+                f3 indirect = mk3(0.f, 0.f, 0.f);
+                if (m0.w > 0.0f) {                               // :337
+                    if (pathtrace) {                             // :187
+                        for (uint32_t p = 0; p < A.paths; p++) {       // :192
+                            f3 d = normalize3(rng_vec3(A, pixel, sample, slot + 2u + p, -1.0f, 1.0f));  // :194
+                            if (dot3(d, hit.normal) < 0.0f) { d = neg3(d); }   // :197-200
+                            const f3 nd = add3(hit.normal, d);         // :202
+                            float tc;
+                            const int ci = closest_gen(hit.pos, nd, tc);   // :204
+                            nrays++;
+                            if (ci >= 0) {                       // :206-209
+                                const float4 cm = mat0[ci];
+                                indirect = add3(indirect, mk3(cm.x, cm.y, cm.z));
                             }
                         }
-                        indirect = scale3(indirect, A.inv_samples);    // :212-213
-                        indirect = scale3(indirect, m0.w);       // :340
                     }
-                    const float value = (cos_theta + 1.f) * .5f; // :343
-                    const float scalar = value * (1.f - m1.x);   // :345
-                    const f3 capture = color_lerp(diffuse, indirect, 1.f - scalar);   // :346
-                    direct = fma3(capture, scalar * .8f, direct);    // :347-349
+                    indirect = scale3(indirect, A.inv_samples);        // :212-213
+                    indirect = scale3(indirect, m0.w);           // :340
                 }
-
-                bounce++;
-                path_ends = (m1.x == 0.0f) || (bounce == A.bounces);   // :353-357, :300
-                if (!path_ends) {
-                    f3 nrm = hit.normal;
-                    if (NOISE) {
-                        const float gain = .2f * m1.y;           // :225
-                        nrm = add3(nrm, rng_vec3(A, pixel, sample, slot + 1u, -gain, gain));   // :226-227
-                    } else {
-                        nrm = add3(nrm, mk3(0.f, 0.f, 0.f));
-                    }
-                    const float k = 2.0f * dot3(dn, nrm);        // fx::reflect, :229
-                    dir = fma3(nrm, -k, dn);                     // :359
-                    if (FROM_HIT) { origin = fma3(hit.normal, .001f, hit.pos); }   // :221-222
-                    slot += slots;
-                }
+                const float value = (cos_theta + 1.f) * .5f;     // :343
+                const float scalar = value * (1.f - m1.x);       // :345
+                const f3 capture = color_lerp(diffuse, indirect, 1.f - scalar);   // :346
+                direct = fma3(capture, scalar * .8f, direct);        // :347-349
             }
 
-            if (path_ends) {
-                const f3 result = scale3(tonemap3(direct), gainf);    // :362, :57-70; :452 (x * 1.0f is x)
-                if (!SPL || k == 0) {
-                    acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
+            bounce++;
+            path_ends = (m1.x == 0.0f) || (bounce == A.bounces);       // :353-357, :300
+            if (!path_ends) {
+                f3 nrm = hit.normal;
+                if (NOISE) {
+                    const float gain = .2f * m1.y;               // :225
+                    nrm = add3(nrm, rng_vec3(A, pixel, sample, slot + 1u, -gain, gain));   // :226-227
                 } else {
-                    float* park = KA->split_scratch + (size_t)(spp_all - 1u - s) * 3u * npix + plocal;   // slot b of the claim
-                    park[0] = result.x; park[npix] = result.y; park[2 * npix] = result.z;
+                    nrm = add3(nrm, mk3(0.f, 0.f, 0.f));
                 }
-                if (!SPL) { s++; } else { have = next_frame(); }
-                bounce = 0;
-                slot = 0;
-                direct = mk3(0.f, 0.f, 0.f);
-                dir = dir0;
-                origin = campos;
+                const float k = 2.0f * dot3(dir, nrm);            // fx::reflect, :229
+                dir = fma3(nrm, -k, dir);                         // :359
+                if (FROM_HIT) { origin = fma3(hit.normal, .001f, hit.pos); }   // :221-222
+                slot += slots;
+            }
+        };
+        auto trip_end = [&]() {
+            const f3 result = scale3(tonemap3(direct), gainf);        // :362, :57-70; :452 (x * 1.0f is x)
+            if (!SPL || k == 0) {
+                acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
+            } else {
+                float* park = KA->split_scratch + (size_t)(spp_all - 1u - s) * 3u * npix + plocal;   // slot b of the claim
+                park[0] = result.x; park[npix] = result.y; park[2 * npix] = result.z;
+            }
+            if (!SPL) { s++; } else { have = next_frame(); }
+            bounce = 0;
+            slot = 0;
+            direct = mk3(0.f, 0.f, 0.f);
+            dir = dir0;
+            origin = campos;
+        };
+
+        if (!DEFER) {
+            while (!SPL ? s < spp_all : have) {
+                path_ends = false;
+                trip_scan();
+                if (idx < 0) { trip_miss(); } else { trip_hit(); }
+                if (path_ends) { trip_end(); }
+            }
+        } else {
+            // The hit piece is most of a trip's instructions and about 38 % of a wave's lanes want it on a trip.  Here a
+            // lane whose ray hit keeps the hit (idx, t, dn: registers the scan filled anyway) and sits out while the
+            // others go on with their next rays, until LUMA_DEFER_NUM / LUMA_DEFER_DEN of the wave's working lanes hold
+            // one (or none is left to scan): then the piece runs once for all of them.  Each lane's own sequence of
+            // operations is what it was; only how the lanes' sequences interleave changes.
+            if (!SPL) { have = s < spp_all; }
+            idx = -1;                                            // >= 0: this lane holds a hit
+            for (;;) {
+                path_ends = false;
+                if (have && idx < 0) {
+                    trip_scan();
+                    if (idx < 0) { trip_miss(); }
+                }
+                const uint32_t holding = __builtin_popcountll(__ballot(idx >= 0));
+                const uint32_t working = __builtin_popcountll(__ballot(have));
+                if (working == 0u) { break; }
+                if (holding * LUMA_DEFER_DEN >= working * LUMA_DEFER_NUM) {
+                    if (idx >= 0) { trip_hit(); idx = -1; }
+                }
+                if (path_ends) {
+                    trip_end();
+                    if (!SPL) { have = s < spp_all; }
+                }
             }
         }
     }
