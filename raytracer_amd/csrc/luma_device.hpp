@@ -113,9 +113,10 @@ LUMA_DEV f3 tonemap3(f3 c)
 
 // pcg3d (Jarzynski & Olano 2020) over (pixel, sample, slot) ^ keys: the counter RNG.
 struct u3 { uint32_t x, y, z; };
-LUMA_DEV u3 pcg3d(uint32_t x, uint32_t y, uint32_t z)
+LUMA_DEV uint32_t pcg_first(uint32_t v) { return v * 1664525u + 1013904223u; }
+// (x already through pcg_first: the ray-per-lane kernel keeps its pixel in that form)
+LUMA_DEV u3 pcg3d_x(uint32_t x, uint32_t y, uint32_t z)
 {
-    x = x * 1664525u + 1013904223u;
     y = y * 1664525u + 1013904223u;
     z = z * 1664525u + 1013904223u;
     x += y * z; y += z * x; z += x * y;
@@ -123,8 +124,15 @@ LUMA_DEV u3 pcg3d(uint32_t x, uint32_t y, uint32_t z)
     x += y * z; y += z * x; z += x * y;
     u3 r; r.x = x; r.y = y; r.z = z; return r;
 }
+LUMA_DEV u3 pcg3d(uint32_t x, uint32_t y, uint32_t z) { return pcg3d_x(pcg_first(x), y, z); }
 
 // fx::Random::vec3(lo, hi) at Renderer.cpp:118 and :226.
+LUMA_DEV f3 rng_vec3_x(const RenderArgs& A, uint32_t pixel_x, uint32_t sample, uint32_t slot, float lo, float hi)
+{
+    u3 h = pcg3d_x(pixel_x, sample ^ A.key[1], slot ^ A.key[2]);
+    const float w = (hi - lo) * 5.9604644775390625e-8f;          // (hi-lo) * 2^-24
+    return mk3(fma_((float)(h.x >> 8), w, lo), fma_((float)(h.y >> 8), w, lo), fma_((float)(h.z >> 8), w, lo));
+}
 LUMA_DEV f3 rng_vec3(const RenderArgs& A, uint32_t pixel, uint32_t sample, uint32_t slot, float lo, float hi)
 {
     u3 h = pcg3d(pixel ^ A.key[0], sample ^ A.key[1], slot ^ A.key[2]);
@@ -595,6 +603,15 @@ extern "C" int luma_dbg_timeline_copy(void* host, size_t bytes)
 #define LUMA_DEFER_NUM 1u
 #define LUMA_DEFER_DEN 2u
 #endif
+#ifndef LUMA_STEAL
+#define LUMA_STEAL 1
+#endif
+#ifndef LUMA_STEAL_SPP_MAX
+#define LUMA_STEAL_SPP_MAX kStealSppMax
+#endif
+#ifndef LUMA_STEAL_POOL
+#define LUMA_STEAL_POOL 256u
+#endif
 #ifndef LUMA_DEFER_WAVES
 #define LUMA_DEFER_WAVES 7
 #endif
@@ -638,7 +655,10 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
 
     // lane -> pixel inside the wave tile; wave -> (frame block k, tile inside the workgroup)
     constexpr bool SPL = SPLIT > 1 || FINE > 0;                  // frames of a pixel are claimed through LDS
-    constexpr bool DEFER = LUMA_DEFER && NS > 0 && !GRID;       // hits wait for company (see the loop skeletons below)
+    // hits wait for company (see the loop skeletons below); not with two lanes per pixel (a band of two of the config #3
+    // frame: 0.942 -> 0.965 ms with it, profiles/r03/ab_deferred_hits.txt) and not for the noise-free one-frame launches
+    constexpr bool DEFER = LUMA_DEFER && NS > 0 && !GRID && NOISE && SPLIT != 2;
+    constexpr bool STEAL = LUMA_STEAL && DEFER && SPLIT == 1;   // lanes out of frames take frames of their wave's other pixels
     constexpr int TILE_H = 64 / TILE_W;
     constexpr int WPK = WAVES / SPLIT;                           // waves per frame block
     constexpr int WGX = wg_waves_x(WPK), WGY = WPK / WGX;
@@ -724,6 +744,9 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
     // others take spp-1, spp-2, ... and park them; a claim is good while front + back < spp, so
     // the two ends meet wherever the lanes' luck puts them and no lane waits on a slower sibling.
     __shared__ uint32_t claim[SPL ? (WPK > WPKF ? WPK : WPKF) * 64 : 1];
+    __shared__ uint32_t steal_pool[STEAL ? WAVES * LUMA_STEAL_POOL * 4u : 1];
+    __shared__ uint8_t steal_pairing[STEAL ? WAVES * 64 : 1];
+    static_assert(!STEAL || WAVES * LUMA_STEAL_POOL * 16u <= 32768u, "the pools of a workgroup's waves fit beside the scene");
     if (SPL && k == 0) { claim[cidx] = 0u; }
     f3 dir0 = mk3(0.f, 0.f, -1.f);
     float blur = 0.f, gainf = 1.f;
@@ -759,7 +782,8 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
         if (k == 0) { acc_r = KA->acc[0][local]; acc_g = KA->acc[1][local]; acc_b = KA->acc[2][local]; }
 
         // per-lane path state (slot == bounce * slots: first RNG slot of the bounce)
-        uint32_t s = (FINE && lone) ? ~0u : 0u, bounce = 0, slot = 0;
+        uint32_t s = (FINE && lone && !STEAL) ? ~0u : 0u, slot = 0;
+        const uint32_t slot_end = slots * A.bounces;              // slot == bounce * slots
         f3 direct = mk3(0.f, 0.f, 0.f);
         f3 dir = dir0;                                           // :293
         f3 origin = campos;                                      // :294, :303
@@ -774,7 +798,24 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
             s = (k == 0) ? f : spp_all - 1u - b;
             return true;
         };
-        bool have = !SPL ? true : next_frame();                  // one lane per pixel everywhere: plainly frames 0 .. spp-1
+        bool have = (!SPL || (STEAL && lone)) ? spp_all > 0u : next_frame();   // one lane per pixel everywhere: plainly frames 0 .. spp-1
+
+        // STEAL (workgroups with one lane per pixel): a lane that has rendered the last unclaimed frame of its own pixel
+        // takes frames from the BACK of another pixel of its wave (spp-1, spp-2, ...) while that pixel's lane goes on from the
+        // front, and leaves each colour in a slot of the wave's pool in LDS; the pixel's lane adds them in frame order when the
+        // wave's loop is over, so the sum is still ((acc + f0) + f1) + ... (Renderer.cpp:457-458).  A wave's lanes run in
+        // lockstep, so all of this is plain reads and writes.  `s_end`: the pixel's own lane renders frames [0, s_end), the
+        // others took [s_end, spp) (0 in a lane that is on another pixel's frame: it has none of its own left).  `taken`: the
+        // pool slot of the latest, i.e. lowest, frame others took from this lane's pixel (each slot links to the one before,
+        // the first to kOwn).  `slot_out`: where this lane's current frame goes (kOwn: into its own accumulator).
+        // Pools of LUMA_STEAL_POOL slots per wave even out 64 frames per pixel; from LUMA_STEAL_SPP_MAX frames on the lanes
+        // differ by more than that and nothing is gained (config #4, 256 frames).
+        constexpr uint32_t kOwn = 0xFFFFu;
+        uint32_t taken = kOwn, slot_out = kOwn, pool_used = 0, s_end = spp_all;
+        bool steals = STEAL && lone && spp_all <= LUMA_STEAL_SPP_MAX;
+        uint32_t rpix = pcg_first(pixel ^ A.key[0]);              // the pixel's word of the RNG counter, through its first step
+        uint32_t* const pool = steal_pool + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * (LUMA_STEAL_POOL * 4u) : 0u);
+        uint8_t* const pairing = steal_pairing + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 64u : 0u);
 
         // One trip of the flat (sample, bounce) loop, in the four pieces the two loop skeletons below arrange:
         // the ray of the trip and its scan; a miss; a hit (the long piece: the indirect ray with its scan, shading,
@@ -786,9 +827,9 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
         bool path_ends = false;
         auto trip_scan = [&]() {
             const uint32_t sample = A.frame_index + s;
-            if (NOISE) { dir = add3(dir, rng_vec3(A, pixel, sample, slot, -blur, blur)); }   // :118-119, :302
+            if (NOISE) { dir = add3(dir, rng_vec3_x(A, rpix, sample, slot, -blur, blur)); }   // :118-119, :302
             else       { dir = add3(dir, mk3(0.f, 0.f, 0.f)); }
-            if (FROM_HIT && bounce > 0) { idx = closest_gen(origin, dir, t); }
+            if (FROM_HIT && slot > 0u) { idx = closest_gen(origin, dir, t); }
             else                        { idx = closest_cam(origin, dir, t); }   // :304
             nrays++;
         };
@@ -811,7 +852,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
                 if (m0.w > 0.0f) {                               // :337
                     if (pathtrace) {                             // :187
                         for (uint32_t p = 0; p < A.paths; p++) {       // :192
-                            f3 d = normalize3(rng_vec3(A, pixel, sample, slot + 2u + p, -1.0f, 1.0f));  // :194
+                            f3 d = normalize3(rng_vec3_x(A, rpix, sample, slot + 2u + p, -1.0f, 1.0f));  // :194
                             if (dot3(d, hit.normal) < 0.0f) { d = neg3(d); }   // :197-200
                             const f3 nd = add3(hit.normal, d);         // :202
                             float tc;
@@ -832,13 +873,12 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
                 direct = fma3(capture, scalar * .8f, direct);        // :347-349
             }
 
-            bounce++;
-            path_ends = (m1.x == 0.0f) || (bounce == A.bounces);       // :353-357, :300
+            path_ends = (m1.x == 0.0f) || (slot + slots == slot_end);  // :353-357, :300 (the bounce just made was the last)
             if (!path_ends) {
                 f3 nrm = hit.normal;
                 if (NOISE) {
                     const float gain = .2f * m1.y;               // :225
-                    nrm = add3(nrm, rng_vec3(A, pixel, sample, slot + 1u, -gain, gain));   // :226-227
+                    nrm = add3(nrm, rng_vec3_x(A, rpix, sample, slot + 1u, -gain, gain));   // :226-227
                 } else {
                     nrm = add3(nrm, mk3(0.f, 0.f, 0.f));
                 }
@@ -850,18 +890,63 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
         };
         auto trip_end = [&]() {
             const f3 result = scale3(tonemap3(direct), gainf);        // :362, :57-70; :452 (x * 1.0f is x)
-            if (!SPL || k == 0) {
+            if (STEAL && lone && slot_out != kOwn) {
+                uint32_t* const e = pool + slot_out * 4u;
+                e[0] = __float_as_uint(result.x); e[1] = __float_as_uint(result.y); e[2] = __float_as_uint(result.z);
+            } else if (!SPL || k == 0) {
                 acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
             } else {
                 float* park = KA->split_scratch + (size_t)(spp_all - 1u - s) * 3u * npix + plocal;   // slot b of the claim
                 park[0] = result.x; park[npix] = result.y; park[2 * npix] = result.z;
             }
-            if (!SPL) { s++; } else { have = next_frame(); }
-            bounce = 0;
+            if (STEAL && lone) {
+                // the pixel's own lane goes on from the front while frames are left; a lane on another pixel's frame
+                // (s_end == 0) looks for the next one in steal_frames
+                if (s + 1u < s_end) { s++; } else { have = false; }
+            } else if (!SPL) { s++; } else { have = next_frame(); }
             slot = 0;
             direct = mk3(0.f, 0.f, 0.f);
             dir = dir0;
             origin = campos;
+        };
+
+        // lanes without a frame are paired, in lane order, with the lanes whose own pixel has unclaimed frames left
+        auto steal_frames = [&]() {
+            const uint64_t wanting = __ballot(!have);
+            if (wanting == 0ull) { return; }
+            const bool gives = have && s + 1u < s_end;
+            const uint64_t giving = __ballot(gives);
+            const uint32_t pairs = min(min((uint32_t)__builtin_popcountll(wanting), (uint32_t)__builtin_popcountll(giving)),
+                                       LUMA_STEAL_POOL - pool_used);
+            // no pixel with a frame to give (none will come: unclaimed frames only go), or the pool is full: that was the last try
+            if (pairs == 0u) { steals = false; return; }
+            const uint64_t mine = have ? giving : wanting;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+            const bool giver = gives && rank < pairs, taker = !have && rank < pairs;
+            if (giver) { pairing[rank] = (uint8_t)lane; }
+            uint32_t from = lane;
+            if (taker) { from = pairing[rank]; }
+            const int at = (int)(from << 2);
+            const uint32_t g_taken = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)taken);
+            const uint32_t g_end = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)s_end);
+            const uint32_t g_pix = (uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)rpix);
+            const float g_dx = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(dir0.x)));
+            const float g_dy = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(dir0.y)));
+            const float g_dz = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(dir0.z)));
+            const float g_blur = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(blur)));
+            const float g_gain = __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute(at, (int)__float_as_uint(gainf)));
+            const uint32_t fresh = pool_used + rank;             // the pair's pool slot
+            if (taker) {
+                slot_out = fresh;
+                pool[fresh * 4u + 3u] = g_taken;                 // links to the frame taken before (a higher one)
+                s = g_end - 1u;                                  // the last frame of the other pixel that nobody has
+                s_end = 0u;
+                rpix = g_pix; dir0 = mk3(g_dx, g_dy, g_dz); blur = g_blur; gainf = g_gain;
+                dir = dir0;
+                have = true;
+            }
+            if (giver) { taken = fresh; s_end--; }
+            pool_used += pairs;
         };
 
         if (!DEFER) {
@@ -893,7 +978,16 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
                 }
                 if (path_ends) {
                     trip_end();
-                    if (!SPL) { have = s < spp_all; }
+                    if (!SPL && !STEAL) { have = s < spp_all; }
+                }
+                if (steals) { steal_frames(); }
+            }
+            if (STEAL && lone) {
+                // the frames other lanes rendered for this pixel, lowest first
+                for (uint32_t e = taken; e != kOwn; ) {
+                    const uint32_t* const q = pool + e * 4u;
+                    acc_r += __uint_as_float(q[0]); acc_g += __uint_as_float(q[1]); acc_b += __uint_as_float(q[2]);
+                    e = q[3];
                 }
             }
         }

@@ -27,6 +27,9 @@ static constexpr uint32_t kSphereParallelMin = 320;   // measured crossover (too
 
 // Scenes of up to this many spheres run ray-per-lane instances with the sphere count as a template constant.
 static constexpr uint32_t kCompileTimeSpheresMax = 16;
+// launches with one lane per pixel and up to this many frames per call: the lanes of a wave take frames of each
+// other's pixels when their own run out (STEAL in render_kernel; plan_split sizes the fine class for it)
+static constexpr uint32_t kStealSppMax = 128;
 
 // FLAG_GRID: scenes with at least this many spheres walk the grid wave-cooperatively (wave_grid_walk).
 static constexpr uint32_t kGridWaveWalkMin = 512;

@@ -164,7 +164,10 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
         // half a round of the coarse waves: a share of 0.45 / rounds, where rounds = coarse waves / wave slots
         // (256 CUs x 28; whole config #3 frame and its band of 2: 4.5 rounds, 10 %, the measured optimum above)
         const double rounds = (double)width * rows / 64.0 * plan.split / (256.0 * 28.0);
-        double share = rounds > 0.0 ? 0.45 / rounds : 0.0;
+        // (one lane per pixel above the class: those waves' lanes take frames of each other's pixels, STEAL in render_kernel,
+        //  and end closer together, so less is left to fill: 0 % 1.643, 4 % 1.610, 6 % 1.602, 8 % 1.607, 10 % 1.611, 15 % 1.620,
+        //  profiles/r03/fine_pct_steal.txt)
+        double share = rounds > 0.0 ? (plan.split == 1 && spp <= kStealSppMax ? 0.27 : 0.45) / rounds : 0.0;
         // (from nine rounds up the drain is too small a part of the launch to pay for the parked frames: config #4's
         //  whole frame, 18 rounds of 256 frames, 25.10 ms with one class, 25.48 with 2 % of its rows in a second;
         //  one of its eight bands, 2.3 rounds: 3.74 -> 3.40, tools/fine_config4.sh)
