@@ -606,16 +606,13 @@ extern "C" int luma_dbg_timeline_copy(void* host, size_t bytes)
 #ifndef LUMA_STEAL
 #define LUMA_STEAL 1
 #endif
-#ifndef LUMA_STEAL_SPP_MAX
-#define LUMA_STEAL_SPP_MAX kStealSppMax
-#endif
 #ifndef LUMA_STEAL_POOL
 #define LUMA_STEAL_POOL 256u
 #endif
 #ifndef LUMA_DEFER_WAVES
 #define LUMA_DEFER_WAVES 7
 #endif
-template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT, bool GRID, int NS = 0, int FINE = 0>
+template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT, bool GRID, int NS = 0, int FINE = 0, bool TAKES = false>
 __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUMA_DEFER_WAVES : 1) void render_kernel(const RenderArgs A)
 {
     // [0,n): camera-origin records; [n,2n): general records; then mat0[n] (float4), mat1[n] (float2)
@@ -658,7 +655,11 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
     // hits wait for company (see the loop skeletons below); not with two lanes per pixel (a band of two of the config #3
     // frame: 0.942 -> 0.965 ms with it, profiles/r03/ab_deferred_hits.txt) and not for the noise-free one-frame launches
     constexpr bool DEFER = LUMA_DEFER && NS > 0 && !GRID && NOISE && SPLIT != 2;
-    constexpr bool STEAL = LUMA_STEAL && DEFER && SPLIT == 1;   // lanes out of frames take frames of their wave's other pixels
+    // TAKES: lanes out of frames take frames of their wave's other pixels (STEAL below); instances of their own, because the
+    // code costs launches that cannot gain from it (config #4, 256 frames per pixel: 22.7 ms without it, 23.4 with it
+    // switched off at run time, profiles/r03/ab_frames_taken.txt); launch_render picks them up to kStealSppMax frames
+    static_assert(!TAKES || (NOISE && SPLIT == 1 && NS > 0 && !GRID), "only these instances exist");
+    constexpr bool STEAL = LUMA_STEAL && TAKES && DEFER;
     constexpr int TILE_H = 64 / TILE_W;
     constexpr int WPK = WAVES / SPLIT;                           // waves per frame block
     constexpr int WGX = wg_waves_x(WPK), WGY = WPK / WGX;
@@ -717,6 +718,9 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
     const uint32_t slots = 2u + A.paths;
     const bool pathtrace = A.mode == MODE_PATHTRACE;
     uint32_t nrays = 0, ntests = 0;                              // ntests: counted under GRID only (else rays * n)
+#ifdef LUMA_DBG_STEAL
+    uint32_t dbg_iters = 0, dbg_events = 0, dbg_taken = 0, dbg_hits = 0;   // tools/steal_stats.py (with LUMA_DBG_TIMELINE)
+#endif
 
     // Renderer::trace_ray (:234-287): linear scan, or the same tests through the grid
     auto closest_cam = [&](f3 o, f3 d, float& t) {
@@ -808,11 +812,11 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
         // others took [s_end, spp) (0 in a lane that is on another pixel's frame: it has none of its own left).  `taken`: the
         // pool slot of the latest, i.e. lowest, frame others took from this lane's pixel (each slot links to the one before,
         // the first to kOwn).  `slot_out`: where this lane's current frame goes (kOwn: into its own accumulator).
-        // Pools of LUMA_STEAL_POOL slots per wave even out 64 frames per pixel; from LUMA_STEAL_SPP_MAX frames on the lanes
-        // differ by more than that and nothing is gained (config #4, 256 frames).
+        // Pools of LUMA_STEAL_POOL slots per wave even out 64 frames per pixel; from kStealSppMax frames on the lanes differ
+        // by more than that and nothing is gained (config #4, 256 frames).
         constexpr uint32_t kOwn = 0xFFFFu;
         uint32_t taken = kOwn, slot_out = kOwn, pool_used = 0, s_end = spp_all;
-        bool steals = STEAL && lone && spp_all <= LUMA_STEAL_SPP_MAX;
+        bool steals = STEAL && lone;
         uint32_t rpix = pcg_first(pixel ^ A.key[0]);              // the pixel's word of the RNG counter, through its first step
         uint32_t* const pool = steal_pool + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * (LUMA_STEAL_POOL * 4u) : 0u);
         uint8_t* const pairing = steal_pairing + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 64u : 0u);
@@ -947,6 +951,9 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
             }
             if (giver) { taken = fresh; s_end--; }
             pool_used += pairs;
+#ifdef LUMA_DBG_STEAL
+            dbg_events++; dbg_taken = pool_used;
+#endif
         };
 
         if (!DEFER) {
@@ -965,6 +972,9 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
             if (!SPL) { have = s < spp_all; }
             idx = -1;                                            // >= 0: this lane holds a hit
             for (;;) {
+#ifdef LUMA_DBG_STEAL
+                dbg_iters++;
+#endif
                 path_ends = false;
                 if (have && idx < 0) {
                     trip_scan();
@@ -974,6 +984,9 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
                 const uint32_t working = __builtin_popcountll(__ballot(have));
                 if (working == 0u) { break; }
                 if (holding * LUMA_DEFER_DEN >= working * LUMA_DEFER_NUM) {
+#ifdef LUMA_DBG_STEAL
+                    dbg_hits++;
+#endif
                     if (idx >= 0) { trip_hit(); idx = -1; }
                 }
                 if (path_ends) {
@@ -1042,7 +1055,12 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
         const uint32_t w = (blockIdx.y * gridDim.x + blockIdx.x) * WAVES + (threadIdx.x >> 6);
         if ((threadIdx.x & 63u) == 0 && w < (1u << 18)) {
             const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));
+#ifdef LUMA_DBG_STEAL
+            dbg_timeline[w] = make_uint4((uint32_t)dbg_t0, (uint32_t)dbg_t1, dbg_iters | (dbg_hits << 16), dbg_taken | (dbg_events << 16));
+            (void)hw; (void)xcc;
+#else
             dbg_timeline[w] = make_uint4((uint32_t)dbg_t0, (uint32_t)dbg_t1, hw, xcc);
+#endif
         }
     }
 #endif

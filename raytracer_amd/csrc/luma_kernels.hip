@@ -340,6 +340,15 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 #undef LUMA_NS16
 #undef LUMA_NS
             k = ns_table[split == 4 ? 2 : split == 2 ? 1 : 0][n - 1][noise][from_hit];
+            // one lane per pixel and enough frames, not too many, for a wave's lanes to even each other out: the TAKES instances
+            const bool takes = noise && split == 1 && args.spp >= 8 && args.spp <= kStealSppMax;
+            if (takes) {
+#define LUMA_NT(N) { render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, false, 1, false, N, 0, true>, render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, true, 1, false, N, 0, true> }
+                static const kernel_t takes_table[16][2] = { LUMA_NT(1), LUMA_NT(2), LUMA_NT(3), LUMA_NT(4), LUMA_NT(5), LUMA_NT(6), LUMA_NT(7), LUMA_NT(8),
+                                                             LUMA_NT(9), LUMA_NT(10), LUMA_NT(11), LUMA_NT(12), LUMA_NT(13), LUMA_NT(14), LUMA_NT(15), LUMA_NT(16) };
+#undef LUMA_NT
+                k = takes_table[n - 1][from_hit];
+            }
             if (args.fine) {                                     // (plan_split: camera-origin bounce rays, up to 8 spheres)
 #define LUMA_NF(W, P, F, N) { render_kernel<kLaneTileW, W, SCENE_LDS_ALL, false, false, P, false, N, F>, \
                               render_kernel<kLaneTileW, W, SCENE_LDS_ALL, true, false, P, false, N, F> }
@@ -347,6 +356,12 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
                             LUMA_NF(W, P, F, 5), LUMA_NF(W, P, F, 6), LUMA_NF(W, P, F, 7), LUMA_NF(W, P, F, 8) }
                 static const kernel_t fine_table[3][8][2] = { LUMA_NF8(4, 1, 4), LUMA_NF8(4, 2, 4), LUMA_NF8(4, 4, 8) };
                 k = fine_table[split == 4 ? 2 : split == 2 ? 1 : 0][n - 1][noise];
+                if (takes) {
+#define LUMA_NTF(N) render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, false, 1, false, N, 4, true>
+                    static const kernel_t takes_fine_table[8] = { LUMA_NTF(1), LUMA_NTF(2), LUMA_NTF(3), LUMA_NTF(4), LUMA_NTF(5), LUMA_NTF(6), LUMA_NTF(7), LUMA_NTF(8) };
+#undef LUMA_NTF
+                    k = takes_fine_table[n - 1];
+                }
 #ifdef LUMA_SWEEP_FINE_PCT
                 if (args.fine == 8 && split < 4 && n == 5) {     // sweep builds: eight lanes under one or two
                     static const kernel_t f8[2][2] = { LUMA_NF(4, 1, 8, 5), LUMA_NF(4, 2, 8, 5) };

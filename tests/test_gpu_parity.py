@@ -129,6 +129,32 @@ def test_pathtrace_multibounce(abi, oracle, W, H, spp, bounces, paths, samples):
     assert st.rays == ost.rays - (spp - 1) * W * H
 
 
+@pytest.mark.parametrize("W,H,spp,n,flags,first", [
+    (64, 2, 8, 5, 0, 0), (97, 13, 16, 5, 0, 0), (160, 90, 33, 5, 0, 7), (200, 40, 64, 5, 0, 0), (64, 8, 128, 5, 0, 3),
+    (33, 5, 129, 5, 0, 0),                       # one frame past kStealSppMax: the twin instance, nothing taken
+    (96, 31, 24, 5, 2, 0),                       # bounce rays from hit points
+    (70, 33, 20, 1, 0, 0), (70, 33, 20, 12, 0, 0), (70, 33, 20, 16, 2, 1),   # other compile-time sphere counts
+    (1920, 9, 48, 5, 0, 0),                      # a fine class under the one-lane rows
+])
+def test_frames_taken_inside_waves_vs_oracle(abi, oracle, W, H, spp, n, flags, first):
+    """One lane per pixel, 8 to 128 frames per call: a lane that has no frame of its own left renders frames from the
+    back of another pixel of its wave, and that pixel's lane adds them in frame order (TAKES instances).
+    Frames and accumulators are the oracle's bit for bit, also on a second call that continues the accumulation."""
+    kw = dict(spp=spp, bounces=5, paths=1, samples=1, mode=1, flags=flags, seed=SEED)
+    scene_g = abi.default_scene() if n == 5 else abi.synthetic_scene(n)
+    scene_o = oracle.default_scene() if n == 5 else oracle.synthetic_scene(n)
+    r = oracle.Renderer(scene_o, oracle.camera(W, H), W, H)
+    with abi.Context(0) as ctx:
+        ctx.set_scene(scene_g); ctx.set_camera(abi.default_camera(W, H)); ctx.set_frame(W, H, 0, H)
+        for call in range(2 if first else 1):
+            p = abi.make_params(W, H, **kw)
+            got, st = ctx.render(p, want_stats=True)
+            r.render(oracle.make_params(W, H, **kw))
+            assert_frames_equal(got, r.target, f"frames taken, call {call}")
+            assert np.array_equal(ctx.read_accum().view(np.uint32), r.accum.view(np.uint32))
+            kw["spp"] = first or spp                 # the second call adds `first` more frames to the same accumulators
+
+
 def test_config3_full_size_band_vs_oracle(abi, oracle):
     """Config #3 at full size (1920x1080, 64 spp, 5 bounces, pathtrace) on the GPU; the
     oracle renders three 4-row bands of the same frame (it needs ~40 s for all of it)."""

@@ -24,8 +24,8 @@ iters = used[:, 2] & 0xFFFF; hits = used[:, 2] >> 16; taken = used[:, 3] & 0xFFF
 print("waves", len(used))
 for name, sel in (("waves that took frames or could (one lane per pixel)", iters > 0),):
     pass
-coarse = np.arange(len(used)) < int(len(used) * 0.88)
-for name, m in (("first 88 % of the waves (coarse class)", coarse), ("the rest (fine class)", ~coarse)):
+coarse = np.arange(len(used)) < int(len(used) * 0.68)          # (the coarse class comes first in the grid; the fine one has four waves per 64 pixels)
+for name, m in (("first 68 % of the waves (coarse class)", coarse), ("the rest (fine class)", ~coarse)):
     print(name)
     for lab, v in (("iterations", iters), ("hit-piece runs", hits), ("frames taken", taken), ("pairing events", events), ("duration us", dur)):
         x = v[m]
