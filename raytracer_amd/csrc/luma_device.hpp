@@ -606,6 +606,9 @@ extern "C" int luma_dbg_timeline_copy(void* host, size_t bytes)
 #ifndef LUMA_STEAL
 #define LUMA_STEAL 1
 #endif
+#ifndef LUMA_DEFER_GENERAL
+#define LUMA_DEFER_GENERAL 0    // the same for run-time sphere counts: 9-12 % slower (profiles/r03/scene_size_sweep_deferral.txt)
+#endif
 #ifndef LUMA_STEAL_POOL
 #define LUMA_STEAL_POOL 256u
 #endif
@@ -652,9 +655,13 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
 
     // lane -> pixel inside the wave tile; wave -> (frame block k, tile inside the workgroup)
     constexpr bool SPL = SPLIT > 1 || FINE > 0;                  // frames of a pixel are claimed through LDS
+    // Parked colours: three planes per slot (a wave's 64 pixels side by side), or with four lanes per pixel, where three
+    // quarters of all frames are parked, a pixel's slots side by side, 12 B each (bands of 4 / 8 of the config #3 frame
+    // 0.494 -> 0.478, 0.257 -> 0.251 ms; the whole frame and its band of 2 lose 0.4 / 1.3 % that way: profiles/r03/ab_park_layout.txt)
+    constexpr bool PARK_BY_PIXEL = SPLIT == 4;
     // hits wait for company (see the loop skeletons below); not with two lanes per pixel (a band of two of the config #3
     // frame: 0.942 -> 0.965 ms with it, profiles/r03/ab_deferred_hits.txt) and not for the noise-free one-frame launches
-    constexpr bool DEFER = LUMA_DEFER && NS > 0 && !GRID && NOISE && SPLIT != 2;
+    constexpr bool DEFER = LUMA_DEFER && (NS > 0 || LUMA_DEFER_GENERAL) && !GRID && NOISE && SPLIT != 2;
     // TAKES: lanes out of frames take frames of their wave's other pixels (STEAL below); instances of their own, because the
     // code costs launches that cannot gain from it (config #4, 256 frames per pixel: 22.7 ms without it, 23.4 with it
     // switched off at run time, profiles/r03/ab_frames_taken.txt); launch_render picks them up to kStealSppMax frames
@@ -819,7 +826,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
         bool steals = STEAL && lone;
         uint32_t rpix = pcg_first(pixel ^ A.key[0]);              // the pixel's word of the RNG counter, through its first step
         uint32_t* const pool = steal_pool + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * (LUMA_STEAL_POOL * 4u) : 0u);
-        uint8_t* const pairing = steal_pairing + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 64u : 0u);
+        volatile uint8_t* const pairing = steal_pairing + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 64u : 0u);
 
         // One trip of the flat (sample, bounce) loop, in the four pieces the two loop skeletons below arrange:
         // the ray of the trip and its scan; a miss; a hit (the long piece: the indirect ray with its scan, shading,
@@ -900,8 +907,13 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
             } else if (!SPL || k == 0) {
                 acc_r += result.x; acc_g += result.y; acc_b += result.z;   // :457-458
             } else {
-                float* park = KA->split_scratch + (size_t)(spp_all - 1u - s) * 3u * npix + plocal;   // slot b of the claim
-                park[0] = result.x; park[npix] = result.y; park[2 * npix] = result.z;
+                if (PARK_BY_PIXEL) {
+                    float* park = KA->split_scratch + ((size_t)plocal * A.park_depth + (spp_all - 1u - s)) * 3u;   // slot b of the claim
+                    park[0] = result.x; park[1] = result.y; park[2] = result.z;
+                } else {
+                    float* park = KA->split_scratch + (size_t)(spp_all - 1u - s) * 3u * npix + plocal;
+                    park[0] = result.x; park[npix] = result.y; park[2 * npix] = result.z;
+                }
             }
             if (STEAL && lone) {
                 // the pixel's own lane goes on from the front while frames are left; a lane on another pixel's frame
@@ -1022,15 +1034,25 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
                 float pr[8], pg[8], pb[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) {
-                    const float* park = E->split_scratch + (size_t)(spp_all - 1u - (f + j)) * 3u * npix + plocal;
-                    pr[j] = park[0]; pg[j] = park[npix]; pb[j] = park[2 * npix];
+                    if (PARK_BY_PIXEL) {
+                        const float* park = E->split_scratch + ((size_t)plocal * A.park_depth + (spp_all - 1u - (f + j))) * 3u;
+                        pr[j] = park[0]; pg[j] = park[1]; pb[j] = park[2];
+                    } else {
+                        const float* park = E->split_scratch + (size_t)(spp_all - 1u - (f + j)) * 3u * npix + plocal;
+                        pr[j] = park[0]; pg[j] = park[npix]; pb[j] = park[2 * npix];
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < 8; j++) { acc_r += pr[j]; acc_g += pg[j]; acc_b += pb[j]; }
             }
             for (; f < spp_all; f++) {
-                const float* park = E->split_scratch + (size_t)(spp_all - 1u - f) * 3u * npix + plocal;
-                acc_r += park[0]; acc_g += park[npix]; acc_b += park[2 * npix];
+                if (PARK_BY_PIXEL) {
+                    const float* park = E->split_scratch + ((size_t)plocal * A.park_depth + (spp_all - 1u - f)) * 3u;
+                    acc_r += park[0]; acc_g += park[1]; acc_b += park[2];
+                } else {
+                    const float* park = E->split_scratch + (size_t)(spp_all - 1u - f) * 3u * npix + plocal;
+                    acc_r += park[0]; acc_g += park[npix]; acc_b += park[2 * npix];
+                }
             }
         }
         E->acc[0][local] = acc_r; E->acc[1][local] = acc_g; E->acc[2][local] = acc_b;
