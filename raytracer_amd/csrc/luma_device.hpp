@@ -606,17 +606,23 @@ extern "C" int luma_dbg_timeline_copy(void* host, size_t bytes)
 #ifndef LUMA_STEAL
 #define LUMA_STEAL 1
 #endif
+#ifndef LUMA_DEFER_SPLIT2
+#define LUMA_DEFER_SPLIT2 0     // with two lanes per pixel: 2.5 % slower (profiles/r03/ab_frames_taken.txt)
+#endif
 #ifndef LUMA_DEFER_GENERAL
 #define LUMA_DEFER_GENERAL 0    // the same for run-time sphere counts: 9-12 % slower (profiles/r03/scene_size_sweep_deferral.txt)
 #endif
 #ifndef LUMA_STEAL_POOL
 #define LUMA_STEAL_POOL 256u
 #endif
+#ifndef LUMA_SPLIT_WAVES
+#define LUMA_SPLIT_WAVES 7
+#endif
 #ifndef LUMA_DEFER_WAVES
 #define LUMA_DEFER_WAVES 7
 #endif
 template <int TILE_W, int WAVES, int SCENE, bool NOISE, bool FROM_HIT, int SPLIT, bool GRID, int NS = 0, int FINE = 0, bool TAKES = false>
-__global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUMA_DEFER_WAVES : 1) void render_kernel(const RenderArgs A)
+__global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? (SPLIT >= 2 ? LUMA_SPLIT_WAVES : LUMA_DEFER_WAVES) : 1) void render_kernel(const RenderArgs A)
 {
     // [0,n): camera-origin records; [n,2n): general records; then mat0[n] (float4), mat1[n] (float2)
     extern __shared__ float4 lds_rec[];
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? LUM
     constexpr bool PARK_BY_PIXEL = SPLIT == 4;
     // hits wait for company (see the loop skeletons below); not with two lanes per pixel (a band of two of the config #3
     // frame: 0.942 -> 0.965 ms with it, profiles/r03/ab_deferred_hits.txt) and not for the noise-free one-frame launches
-    constexpr bool DEFER = LUMA_DEFER && (NS > 0 || LUMA_DEFER_GENERAL) && !GRID && NOISE && SPLIT != 2;
+    constexpr bool DEFER = LUMA_DEFER && (NS > 0 || LUMA_DEFER_GENERAL) && !GRID && NOISE && (SPLIT != 2 || LUMA_DEFER_SPLIT2);
     // TAKES: lanes out of frames take frames of their wave's other pixels (STEAL below); instances of their own, because the
     // code costs launches that cannot gain from it (config #4, 256 frames per pixel: 22.7 ms without it, 23.4 with it
     // switched off at run time, profiles/r03/ab_frames_taken.txt); launch_render picks them up to kStealSppMax frames
