@@ -144,6 +144,12 @@ int luma_hip_set_frame_striped(luma_ctx* ctx, uint32_t width, uint32_t height, u
  * scene for its tables).  No counterpart in the reference. */
 int luma_hip_reserve(luma_ctx* ctx, uint32_t max_spp);
 int luma_hip_alloc_count(luma_ctx* ctx, uint64_t* count);
+/* The most device memory the context may hold for parked frames (default and largest value: 2 GiB).  A render call
+ * whose band would want more with several lanes per pixel runs one lane per pixel instead, with as many rows in its
+ * fine class as fit (luma_stats.split_refused; what luma_split_plan_describe reports for the same budget); the frame
+ * is the same bit for bit.  For callers that share the GPU's memory with something larger.  Takes effect at the next
+ * render or luma_hip_reserve call; memory already held is kept.  No counterpart in the reference. */
+int luma_hip_set_park_limit(luma_ctx* ctx, uint64_t bytes);
 
 /* The camera.moved branch, Renderer.cpp:377-390: frame_count = 1, accumulated_data = 0. */
 int luma_hip_reset(luma_ctx* ctx);

@@ -33,7 +33,7 @@ SYMBOLS = [
     "luma_hip_host_alloc", "luma_hip_host_free", "luma_grid_describe", "luma_hip_read_target",
     "luma_hip_render_device_noalloc",
     "luma_hip_group_render_device", "luma_hip_group_frame_device", "luma_hip_group_read_frame",
-    "luma_hip_reserve", "luma_hip_alloc_count", "luma_hip_group_reserve", "luma_view_grid_describe",
+    "luma_hip_reserve", "luma_hip_alloc_count", "luma_hip_set_park_limit", "luma_hip_group_reserve", "luma_view_grid_describe",
     "luma_split_plan_describe", "luma_gather_plan_describe",
 ]
 
@@ -111,6 +111,7 @@ def lib():
         "luma_hip_reset": (C.c_int, [ctx]),
         "luma_hip_reserve": (C.c_int, [ctx, C.c_uint32]),
         "luma_hip_alloc_count": (C.c_int, [ctx, C.POINTER(C.c_uint64)]),
+        "luma_hip_set_park_limit": (C.c_int, [ctx, C.c_uint64]),
         "luma_hip_render": (C.c_int, [ctx, C.POINTER(Params), u32p, C.POINTER(Stats)]),
         "luma_hip_render_device": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]),
         "luma_hip_render_device_noalloc": (C.c_int, [ctx, C.POINTER(Params), C.c_void_p, C.c_void_p]),
@@ -333,6 +334,9 @@ class Context:
 
     def reserve(self, max_spp):
         check(lib().luma_hip_reserve(self._h, max_spp), "luma_hip_reserve")
+
+    def set_park_limit(self, nbytes):
+        check(lib().luma_hip_set_park_limit(self._h, nbytes), "luma_hip_set_park_limit")
 
     def alloc_count(self):
         n = C.c_uint64()

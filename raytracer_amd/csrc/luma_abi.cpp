@@ -90,6 +90,7 @@ void free_dev(T*& p)
 
 struct luma_ctx {
     int device = 0;
+    size_t park_limit = size_t(2) << 30;        // luma_hip_set_park_limit
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
 
@@ -345,7 +346,7 @@ int enqueue_render(luma_ctx* ctx, const luma_params* p, uint32_t* target_dev, hi
     args.target_mirror = target_mirror;
     args.mirror_is_frame = mirror_is_frame ? 1u : 0u;
     // (more than 2 GiB of parking is not worth it: such calls run one lane per pixel, reported in luma_stats)
-    const luma::SplitPlan plan = split_plan(ctx, p->spp, grid, (p->flags & LUMA_FLAG_ORIGIN_FROM_HIT) != 0, kMaxSplitBytes);
+    const luma::SplitPlan plan = split_plan(ctx, p->spp, grid, (p->flags & LUMA_FLAG_ORIGIN_FROM_HIT) != 0, ctx->park_limit);
     ctx->last_split_refused = plan.refused;
     if (plan.park_bytes > ctx->split_bytes) {
         // only when luma_hip_reserve was not called (or named fewer spp): the first such call pays
@@ -689,6 +690,15 @@ int luma_hip_reset(luma_ctx* ctx)
     return LUMA_OK;
 }
 
+int luma_hip_set_park_limit(luma_ctx* ctx, uint64_t bytes)
+{
+    const char* who = "luma_hip_set_park_limit";
+    if (!ctx) { return fail(LUMA_E_ARG, who, "null context"); }
+    if (bytes > kMaxSplitBytes) { return fail(LUMA_E_ARG, who, "the limit is at most 2 GiB"); }
+    ctx->park_limit = static_cast<size_t>(bytes);
+    return LUMA_OK;
+}
+
 int luma_hip_reserve(luma_ctx* ctx, uint32_t max_spp)
 {
     const char* who = "luma_hip_reserve";
@@ -705,15 +715,15 @@ int luma_hip_reserve(luma_ctx* ctx, uint32_t max_spp)
     size_t need = 0;
     for (int grid = 0; grid < 2; grid++) {
         for (int from_hit = 0; from_hit < 2; from_hit++) {
-            const luma::SplitPlan at_max = split_plan(ctx, max_spp, grid != 0, from_hit != 0, kMaxSplitBytes);
+            const luma::SplitPlan at_max = split_plan(ctx, max_spp, grid != 0, from_hit != 0, ctx->park_limit);
             need = std::max(need, at_max.park_bytes);
             if (at_max.refused) {
                 uint32_t lo = 0, hi = max_spp;                   // largest spp below max_spp whose plan is not refused
                 while (hi - lo > 1) {
                     const uint32_t mid = lo + (hi - lo) / 2;
-                    if (split_plan(ctx, mid, grid != 0, from_hit != 0, kMaxSplitBytes).refused) { hi = mid; } else { lo = mid; }
+                    if (split_plan(ctx, mid, grid != 0, from_hit != 0, ctx->park_limit).refused) { hi = mid; } else { lo = mid; }
                 }
-                if (lo >= 1) { need = std::max(need, split_plan(ctx, lo, grid != 0, from_hit != 0, kMaxSplitBytes).park_bytes); }
+                if (lo >= 1) { need = std::max(need, split_plan(ctx, lo, grid != 0, from_hit != 0, ctx->park_limit).park_bytes); }
             }
         }
     }

@@ -155,6 +155,33 @@ def test_frames_taken_inside_waves_vs_oracle(abi, oracle, W, H, spp, n, flags, f
             kw["spp"] = first or spp                 # the second call adds `first` more frames to the same accumulators
 
 
+@pytest.mark.parametrize("W,H,spp,n,flags,limit", [(640, 360, 64, 5, 0, 8 << 20), (512, 300, 100, 5, 0, 0), (640, 360, 48, 3, 2, 1 << 20),
+                                                   (97, 55, 128, 16, 0, 0)])
+def test_frames_taken_on_a_small_frame_vs_the_whole_oracle_frame(abi, oracle, W, H, spp, n, flags, limit):
+    """The TAKES instances run where a band has one lane per pixel: from 1.5 M pixels, or where four lanes' parking does
+    not fit its budget.  luma_hip_set_park_limit makes small frames such bands (with a fine class as large as the limit
+    holds, or none), so the oracle can render all of them: every pixel and accumulator equal, and again after a second
+    call that continues the accumulation."""
+    plan = abi.split_plan(W, H, spp, n, flags=flags, park_budget=limit)
+    assert plan.lanes == 1 and plan.refused == 1 and plan.park_bytes <= limit
+    kw = dict(spp=spp, bounces=5, paths=1, samples=1, mode=1, flags=flags, seed=SEED)
+    scene_g = abi.default_scene() if n == 5 else abi.synthetic_scene(n)
+    scene_o = oracle.default_scene() if n == 5 else oracle.synthetic_scene(n)
+    r = oracle.Renderer(scene_o, oracle.camera(W, H), W, H)
+    with abi.Context(0) as ctx:
+        ctx.set_scene(scene_g); ctx.set_camera(abi.default_camera(W, H)); ctx.set_frame(W, H, 0, H)
+        ctx.set_park_limit(limit)
+        for spp_call in (spp, 9):
+            kw["spp"] = spp_call
+            got, st = ctx.render(abi.make_params(W, H, **kw), want_stats=True)
+            r.render(oracle.make_params(W, H, **kw))
+            assert st.lanes_per_pixel == 1
+            assert_frames_equal(got, r.target, f"frames taken, small frame, {spp_call} spp")
+            assert np.array_equal(ctx.read_accum().view(np.uint32), r.accum.view(np.uint32))
+        with pytest.raises(abi.LumaError):
+            ctx.set_park_limit(3 << 30)
+
+
 def test_config3_full_size_band_vs_oracle(abi, oracle):
     """Config #3 at full size (1920x1080, 64 spp, 5 bounces, pathtrace) on the GPU; the
     oracle renders three 4-row bands of the same frame (it needs ~40 s for all of it)."""
