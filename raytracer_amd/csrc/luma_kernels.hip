@@ -96,13 +96,35 @@ bool persistent_launch(uint32_t n_spheres, bool grid)
     return grid ? grid_wave_walk(n_spheres) : sphere_parallel_scene(n_spheres);
 }
 
-static uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid)
+// Launches whose one-lane-per-pixel workgroups run the TAKES instances (launch_render): the lanes of a wave take frames of
+// each other's pixels.  (Without LUMA_FLAG_NOISE_OFF, which plan_split is not told about: a noise-free launch of many
+// frames renders the same frame many times, and is planned as if it could.)
+static bool fine_class_launch(uint32_t split, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit);
+
+static bool takes_launch(uint32_t spp, uint32_t n_spheres, bool grid)
+{
+    return !grid && n_spheres >= 1 && n_spheres <= kCompileTimeSpheresMax && spp >= 8 && spp <= kStealSppMax;
+}
+
+static uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_spheres, bool grid, bool from_hit)
 {
     if (persistent_launch(n_spheres, grid)) { return 1; }
     // measured on MI355X, bands of the 1080p x 64 spp frame (kernel ms for 1 / 2 / 4 lanes per pixel):
     // 2.07M px 2.09 / 2.13 / 2.32, 1.04M px 1.17 / 1.11 / 1.17, 518k px 0.66 / 0.61 / 0.60,
     // 259k px 0.50 / 0.36 / 0.33
     uint32_t split = band_pixels >= 1500000 ? 1u : band_pixels >= 750000 ? 2u : 4u;
+    // Round 3: where lanes take frames inside their waves one lane per pixel needs no parking and keeps 56 % of its lanes
+    // busy, and wins down to bands that fill the GPU once; kernel ms of bands of 2 / 3 / 4 / 5 / 6 of the 1080p x 64 spp
+    // frame (1.04M / 691k / 518k / 415k / 346k px) with 4 lanes: 0.960 / 0.632 / 0.483 / 0.372 / 0.326, with 2: 0.970 / 0.645 /
+    // 0.490 / 0.385 / 0.344, with 1 and a fine class: 0.810 / 0.577 / 0.453 / 0.354 / 0.329, with 1 and none: 0.881 / - / 0.489
+    // (tools/split_sweep.sh, split_sweep2.sh, profiles/r03/split_sweep.txt)
+    if (takes_launch(spp, n_spheres, grid)) {
+        const bool fine = fine_class_launch(1, spp, n_spheres, grid, from_hit);
+        split = band_pixels >= (fine ? 380000u : 600000u) ? 1u : 4u;
+    }
+#ifdef LUMA_SWEEP_FINE_PCT
+    if (const char* e = getenv("LUMA_FORCE_SPLIT")) { split = (uint32_t)atoi(e); }   // sweep builds: lanes per pixel by hand
+#endif
     while (split > spp) { split >>= 1; }
     // the claim word holds two 16-bit counts, and a failed claim still increments its half: the
     // front can reach spp + 1 and the back spp + split - 1
@@ -145,7 +167,7 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
 {
     SplitPlan plan;
     plan.fine_row0 = rows;
-    plan.split = choose_split((size_t)width * rows, spp, n_spheres, grid);
+    plan.split = choose_split((size_t)width * rows, spp, n_spheres, grid, from_hit);
     // the most lanes per pixel this launch may run (the fine class has twice the coarse one's, four at least)
     const auto lanes_most = [&](uint32_t split) {
         return fine_class_launch(split, spp, n_spheres, grid, from_hit) ? (split == 4 ? 8u : 4u) : split;
@@ -167,11 +189,16 @@ SplitPlan plan_split(uint32_t width, uint32_t rows, uint32_t spp, uint32_t n_sph
         // (one lane per pixel above the class: those waves' lanes take frames of each other's pixels, STEAL in render_kernel,
         //  and end closer together, so less is left to fill: 0 % 1.643, 4 % 1.610, 6 % 1.602, 8 % 1.607, 10 % 1.611, 15 % 1.620,
         //  profiles/r03/fine_pct_steal.txt)
-        double share = rounds > 0.0 ? (plan.split == 1 && spp <= kStealSppMax ? 0.27 : 0.45) / rounds : 0.0;
+        double share = rounds > 0.0 ? 0.45 / rounds : 0.0;
+        // (and bands of one or two rounds want more than that rule leaves them: band of 4, 1.13 rounds, 0.476 ms with 24 % of its
+        //  rows in the class, 0.462 with 30 %, 0.453 with 40 %, 0.457 with 50 %; band of 3, 1.5 rounds, 0.581 / 0.577 / 0.588 with
+        //  18 / 30 / 40 %; band of 2, 2.26 rounds: 0.861 / 0.809 / 0.820 with 6 / 12 / 20 %)
+        const bool takes = plan.split == 1 && takes_launch(spp, n_spheres, grid);
+        if (takes) { share = 0.27 / rounds + 0.15 * std::max(0.0, 2.0 - rounds); }
         // (from nine rounds up the drain is too small a part of the launch to pay for the parked frames: config #4's
         //  whole frame, 18 rounds of 256 frames, 25.10 ms with one class, 25.48 with 2 % of its rows in a second;
         //  one of its eight bands, 2.3 rounds: 3.74 -> 3.40, tools/fine_config4.sh)
-        share = share < 0.05 ? 0.0 : share > 0.30 ? 0.30 : share;
+        share = share < 0.05 ? 0.0 : std::min(share, takes ? 0.40 : 0.30);
         // Four lanes per pixel above: eight in the fine class, two of each pixel side by side in every wave of a
         // four-wave workgroup (HALF in render_kernel; eight-wave workgroups lose more than the class gains).  Those
         // workgroups cost more per frame, and a few of them are enough to fill the drain of 0.1 ms workgroups:

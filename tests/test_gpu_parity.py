@@ -510,7 +510,8 @@ def test_bands_equal_full_frame(abi, oracle, nbands):
     assert rays == fst.rays
 
 
-@pytest.mark.parametrize("W,H,spp,lanes", [(1603, 1001, 9, 1), (1201, 701, 13, 2), (1537, 977, 8, 1)])
+# (two lanes per pixel under the class only where no frames are taken inside waves: more than 128 frames per call)
+@pytest.mark.parametrize("W,H,spp,lanes", [(1603, 1001, 9, 1), (1201, 701, 13, 1), (1201, 701, 130, 2), (1537, 977, 8, 1)])
 def test_two_classes_of_workgroups_equal_small_bands(abi, W, H, spp, lanes):
     """Frames large enough for the fine class above one or two lanes per pixel (luma_kernels.hip plan_split: the last
     rows of the launch run four lanes per pixel, the rows above them `lanes`), with sides that are no multiple of
@@ -724,9 +725,10 @@ def test_reserve_covers_grid_launches_and_smaller_calls_after_a_refused_plan(abi
     with abi.Context(0) as ctx:
         ctx.set_scene(abi.default_scene()); ctx.set_camera(abi.default_camera(W, H))
         ctx.set_frame_striped(W, H, 15, 0, 8)
-        assert abi.split_plan(W, 270, 256, 5).refused == 1 and abi.split_plan(W, 270, 128, 5).refused == 0
+        # (160 frames: past kStealSppMax, so two lanes per pixel and the whole band parks; up to 128 it would be one lane)
+        assert abi.split_plan(W, 270, 256, 5).refused == 1 and abi.split_plan(W, 270, 160, 5).refused == 0
         ctx.reserve(256)
-        st = ctx.render_device(abi.make_params(W, H, spp=128, bounces=1, paths=1, samples=1, mode=0, flags=0, seed=SEED), want_stats=True)
+        st = ctx.render_device(abi.make_params(W, H, spp=160, bounces=1, paths=1, samples=1, mode=0, flags=0, seed=SEED), want_stats=True)
         assert st.lanes_per_pixel > 1 and st.split_refused == 0 and ctx.alloc_count() == 0
 
 

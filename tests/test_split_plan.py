@@ -16,17 +16,29 @@ def geometry_ok(p, rows):
     assert p.park_row0 == (0 if p.lanes > 1 else p.fine_row0)
 
 
-@pytest.mark.parametrize("rows,lanes,fine", [(1080, 1, 4), (540, 2, 4), (270, 4, 8), (135, 4, 8)])
-def test_config3_frame_and_its_bands(abi, rows, lanes, fine):
+@pytest.mark.parametrize("rows,lanes,fine,share", [(1080, 1, 4, 0.06), (540, 1, 4, 0.12), (360, 1, 4, 0.255), (270, 1, 4, 0.37),
+                                                   (216, 1, 4, 0.40), (180, 4, 8, 0.05), (135, 4, 8, 0.05)])
+def test_config3_frame_and_its_bands(abi, rows, lanes, fine, share):
+    # 64 frames per call: the lanes of one-lane-per-pixel waves take frames of each other's pixels, so one lane per pixel
+    # serves down to the bands that fill the GPU once (~380k pixels); below that four lanes per pixel and eight in the class
     p = abi.split_plan(W, rows, 64, 5)
     assert (p.lanes, p.fine_lanes, p.refused) == (lanes, fine, 0)
     geometry_ok(p, rows)
     fine_rows = rows - p.fine_row0
-    share = {1: 0.06, 2: 0.10, 4: 0.05}[lanes]           # one lane per pixel: the lanes share frames inside their waves, less to fill
-    assert abs(fine_rows - share * rows) <= 4, (fine_rows, rows)
+    assert abs(fine_rows - share * rows) <= 6, (fine_rows, rows)
     # only frames claimed from the back are parked: (L-1)/L of them plus a margin, for the most lanes per pixel of the launch
     assert p.park_depth == {4: 52, 8: 58}[fine]
     assert p.park_bytes == p.park_depth * 12 * W * (rows - p.park_row0)
+
+
+def test_lanes_per_pixel_where_no_frames_are_taken(abi):
+    # more than kStealSppMax frames per call, or fewer than 8: the round-2 rule (1 lane from 1.5M pixels, 2 from 750k, else 4)
+    assert [abi.split_plan(W, rows, 130, 5).lanes for rows in (1080, 540, 270)] == [1, 2, 4]
+    assert [abi.split_plan(W, rows, 4, 5).lanes for rows in (1080, 540, 270)] == [1, 2, 4]
+    # hit-point origins have no fine class: one lane per pixel from 600k pixels
+    assert [abi.split_plan(W, rows, 64, 5, flags=abi.FLAG_ORIGIN_FROM_HIT).lanes for rows in (1080, 540, 360, 270)] == [1, 1, 1, 4]
+    # more than 16 spheres: run-time sphere counts, no TAKES instances
+    assert [abi.split_plan(W, rows, 64, 64).lanes for rows in (1080, 540, 270)] == [1, 2, 4]
 
 
 def test_no_fine_class_below_eight_frames_or_with_many_rounds(abi):
