@@ -135,8 +135,8 @@ int luma_hip_set_frame_striped(luma_ctx* ctx, uint32_t width, uint32_t height, u
 
 /* Set-up for render calls of up to max_spp frames on the current scene and frame: allocates now
  * whatever device scratch such calls use (the planes in which small bands, and the last rows of
- * large ones, park frames rendered by several lanes of one pixel: spp * 12 B per such pixel, 153 MB
- * for a 1080p frame of 64 spp, 199 MB for an eighth of it), so that luma_hip_render* itself never allocates or synchronises the
+ * large ones, park frames rendered by several lanes of one pixel: luma_split_plan.park_depth * 12 B per such
+ * pixel, 73 MB for a 1080p frame of 64 spp (its last 64 rows), 172 MB for an eighth of it (every pixel)), so that luma_hip_render* itself never allocates or synchronises the
  * device for it.  Optional: without it the first render call that needs more scratch than the
  * context holds allocates it.  Call again after luma_hip_set_frame* / luma_hip_set_scene.
  * luma_hip_alloc_count reports how many device allocations render calls have made on the context
