@@ -30,6 +30,12 @@ static constexpr uint32_t kCompileTimeSpheresMax = 16;
 // launches with one lane per pixel and up to this many frames per call: the lanes of a wave take frames of each
 // other's pixels when their own run out (STEAL in render_kernel; plan_split sizes the fine class for it)
 static constexpr uint32_t kStealSppMax = 128;
+// ... and from this many: 1080p calls of 2 / 3 / 4 / 7 frames 0.134 / 0.169 / 0.200 / 0.284 -> 0.123 / 0.150 / 0.177 / 0.255 ms
+// (tools/low_spp_probe.py, profiles/r03/small_probes.txt); the lanes-per-pixel rule and the fine class start at 8 frames
+#ifndef LUMA_STEAL_SPP_MIN
+#define LUMA_STEAL_SPP_MIN 2
+#endif
+static constexpr uint32_t kStealSppMin = LUMA_STEAL_SPP_MIN;
 
 // FLAG_GRID: scenes with at least this many spheres walk the grid wave-cooperatively (wave_grid_walk).
 static constexpr uint32_t kGridWaveWalkMin = 512;

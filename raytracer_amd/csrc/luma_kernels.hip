@@ -368,7 +368,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 #undef LUMA_NS
             k = ns_table[split == 4 ? 2 : split == 2 ? 1 : 0][n - 1][noise][from_hit];
             // one lane per pixel and enough frames, not too many, for a wave's lanes to even each other out: the TAKES instances
-            const bool takes = noise && split == 1 && args.spp >= 8 && args.spp <= kStealSppMax;
+            const bool takes = noise && split == 1 && args.spp >= kStealSppMin && args.spp <= kStealSppMax;
             if (takes) {
 #define LUMA_NT(N) { render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, false, 1, false, N, 0, true>, render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, true, 1, false, N, 0, true> }
                 static const kernel_t takes_table[16][2] = { LUMA_NT(1), LUMA_NT(2), LUMA_NT(3), LUMA_NT(4), LUMA_NT(5), LUMA_NT(6), LUMA_NT(7), LUMA_NT(8),

@@ -115,7 +115,7 @@ for n in range(1, 9):
         pitch=float(_rng.uniform(-0.5, 0.5)), yaw=float(_rng.uniform(-1, 1)), calls=2))
 
 
-# one lane per pixel with frames taken inside the waves (TAKES instances: 8 to 128 frames per call, 1 to 16 spheres, noise
+# one lane per pixel with frames taken inside the waves (TAKES instances: 2 to 128 frames per call, 1 to 16 spheres, noise
 # on): small frames are made such bands with luma_hip_set_park_limit (0: no fine class; some MiB: a partial or whole one);
 # scales that leave the lean sqrt / division windows, tie-prone kinds, hit-point origins, two accumulating calls
 for case in range(24):
@@ -123,7 +123,7 @@ for case in range(24):
     n = int(_rng.choice([1, 2, 5, 8, 9, 16]))
     CASES.append(dict(
         id=f"takes{case}-{kind}-n{n}", kind=kind, n=n, scale=float(_rng.choice([1.0, 1.0, 1e-3, 3e4])), seed=int(_rng.integers(1, 2**31)),
-        W=int(_rng.integers(30, 200)), H=int(_rng.integers(3, 60)), spp=int(_rng.choice([8, 9, 17, 40, 64, 128])),
+        W=int(_rng.integers(30, 200)), H=int(_rng.integers(3, 60)), spp=int(_rng.choice([2, 3, 5, 8, 9, 17, 40, 64, 128])),
         bounces=int(_rng.integers(1, 7)), paths=int(_rng.integers(0, 3)), samples=int(_rng.integers(1, 3)), mode=int(case % 5 != 0),
         flags=int(_rng.choice([0, 0, 2, 4, 8, 2 | 16])), park_limit=int(_rng.choice([0, 0, 1 << 20, 64 << 20])),
         rng_seed=int(_rng.integers(0, 2**63)), posed=bool(case % 3 == 0), pos=[float(v) for v in _rng.uniform(-2, 2, size=3)],
