@@ -585,6 +585,8 @@ enum : int { SCENE_GLOBAL = 0, SCENE_LDS_ALL = 2 };
 // that the launch does not drain for as long as one of the long workgroups takes (plan_split has the
 // measurements).  With FINE the grid is one-dimensional; the coarse class (SPLIT lanes per pixel, a plain
 // frame loop without claims when SPLIT == 1) comes first in it.
+// TAKES gives the workgroups with one lane per pixel the frame taking described at STEAL in the kernel (launch_render
+// picks these instances for noisy launches of kStealSppMin .. kStealSppMax frames per call).
 // (GRID: the walk waits on dependent loads, so six waves per SIMD with ~40 B of spills beat four
 //  without: 2.93 -> 2.15 ms at 4096 spheres; five: 2.42, seven: 2.12 / 3.05 at 65536, eight: 2.60)
 #ifdef LUMA_DBG_TIMELINE
@@ -596,6 +598,8 @@ extern "C" int luma_dbg_timeline_copy(void* host, size_t bytes)
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dbg_timeline), bytes);
 }
 #endif
+// Build-time switches of the two round-3 loop forms (DEFER: hits wait for company; STEAL: lanes take frames inside their
+// wave), for the A/B builds under profiles/r03 (make EXTRA=-D...); the values below are the library's.
 #ifndef LUMA_DEFER
 #define LUMA_DEFER 1
 #endif
