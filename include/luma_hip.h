@@ -182,8 +182,9 @@ int luma_hip_render_device(luma_ctx* ctx, const luma_params* params, uint32_t* t
  * process end.  The call makes no hipMalloc / hipFree and calls no allocating routine; it returns
  * without waiting (no luma_stats: its rays are not added to the context's counters).
  * Limits: a call whose scratch need exceeds the array is rejected with LUMA_E_ARG and a message
- * giving both sizes (need = 32 KiB + slots * 12 B * band pixels, slots = luma_split_plan.park_depth: about (L-1)/L of spp for L lanes per pixel, for bands under 1.5 M pixels of scenes
- * under 320 spheres, 32 KiB otherwise; larger bands park only their last rows, as many as fit the
+ * giving both sizes (need = 32 KiB + slots * 12 B * band pixels, slots = luma_split_plan.park_depth: about (L-1)/L of spp for L lanes per pixel, for bands that run several lanes per pixel
+ * (luma_split_plan.lanes > 1: scenes under 320 spheres; under 1.5 M pixels, or under ~380k pixels for calls of 8-128 frames on scenes of
+ * up to 16 spheres, where one lane per pixel serves further down), 32 KiB otherwise; larger bands park only their last rows, as many as fit the
  * array): render the frames in several calls of fewer spp, which accumulates to the same bits.  LUMA_FLAG_GRID is rejected (LUMA_E_ARG): its tables are allocated
  * on first use and its kernels spill registers, which makes the HIP runtime set up memory of its
  * own at dispatch; the kernels behind every other flag use no private memory.  All calls
