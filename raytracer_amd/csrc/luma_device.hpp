@@ -675,8 +675,8 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? (SP
     // TAKES: lanes out of frames take frames of their wave's other pixels (STEAL below); instances of their own, because the
     // code costs launches that cannot gain from it (config #4, 256 frames per pixel: 22.7 ms without it, 23.4 with it
     // switched off at run time, profiles/r03/ab_frames_taken.txt); launch_render picks them up to kStealSppMax frames
-    static_assert(!TAKES || (NOISE && SPLIT == 1 && NS > 0 && !GRID), "only these instances exist");
-    constexpr bool STEAL = LUMA_STEAL && TAKES && DEFER;
+    static_assert(!TAKES || (NOISE && SPLIT == 1 && !GRID && (NS > 0 || FINE == 0)), "only these instances exist");
+    constexpr bool STEAL = LUMA_STEAL && TAKES;                  // (with the plain loop where DEFER is off: run-time sphere counts)
     constexpr int TILE_H = 64 / TILE_W;
     constexpr int WPK = WAVES / SPLIT;                           // waves per frame block
     constexpr int WGX = wg_waves_x(WPK), WGY = WPK / WGX;
@@ -978,12 +978,32 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? (SP
 #endif
         };
 
-        if (!DEFER) {
+        if (!DEFER && !STEAL) {
             while (!SPL ? s < spp_all : have) {
                 path_ends = false;
                 trip_scan();
                 if (idx < 0) { trip_miss(); } else { trip_hit(); }
                 if (path_ends) { trip_end(); }
+            }
+        } else if (!DEFER) {
+            // the plain loop with frames taken inside the wave (scenes with a run-time sphere count: a trip costs a whole scan
+            // however few lanes are left, so every trip the wave saves counts in full)
+            for (;;) {
+                path_ends = false;
+                if (have) {
+                    trip_scan();
+                    if (idx < 0) { trip_miss(); } else { trip_hit(); }
+                    if (path_ends) { trip_end(); }
+                }
+                if (steals) { steal_frames(); }
+                if (__ballot(have) == 0ull) { break; }
+            }
+            if (lone) {
+                for (uint32_t e = taken; e != kOwn; ) {
+                    const uint32_t* const q = pool + e * 4u;
+                    acc_r += __uint_as_float(q[0]); acc_g += __uint_as_float(q[1]); acc_b += __uint_as_float(q[2]);
+                    e = q[3];
+                }
             }
         } else {
             // The hit piece is most of a trip's instructions and about 38 % of a wave's lanes want it on a trip.  Here a

@@ -100,6 +100,11 @@
 #define LUMA_LIST_TAKES_9_16(X) LUMA_LIST_TAKES_N(X, 9) LUMA_LIST_TAKES_N(X, 10) LUMA_LIST_TAKES_N(X, 11) LUMA_LIST_TAKES_N(X, 12) \
     LUMA_LIST_TAKES_N(X, 13) LUMA_LIST_TAKES_N(X, 14) LUMA_LIST_TAKES_N(X, 15) LUMA_LIST_TAKES_N(X, 16)
 
+// ... and the run-time-sphere-count instances with frames taken (17 to kTakesGeneralSpheresMax spheres)
+#define LUMA_LIST_TAKES_GENERAL(X) \
+    X(render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, false, 1, false, 0, 0, true>) \
+    X(render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, true, 1, false, 0, 0, true>)
+
 // sphere-parallel scan
 #define LUMA_LIST_SP(X) \
     X(render_kernel_sp<kTileW, 4, false, false>) \
@@ -126,4 +131,4 @@
     X(render_kernel_sp<kTileW, 16, true, false, true, 2>) \
     X(render_kernel_sp<kTileW, 16, true, true, true, 2>)
 
-#define LUMA_LIST_ALL(X) LUMA_LIST_GENERAL(X) LUMA_LIST_GRID(X) LUMA_LIST_NS_1_4(X) LUMA_LIST_NS_5_8(X) LUMA_LIST_NS_9_12(X) LUMA_LIST_NS_13_16(X) LUMA_LIST_FINE_1_4(X) LUMA_LIST_FINE_5_8(X) LUMA_LIST_TAKES_1_8(X) LUMA_LIST_TAKES_FINE(X) LUMA_LIST_TAKES_9_16(X) LUMA_LIST_SP(X) LUMA_LIST_COOP(X)
+#define LUMA_LIST_ALL(X) LUMA_LIST_GENERAL(X) LUMA_LIST_GRID(X) LUMA_LIST_NS_1_4(X) LUMA_LIST_NS_5_8(X) LUMA_LIST_NS_9_12(X) LUMA_LIST_NS_13_16(X) LUMA_LIST_FINE_1_4(X) LUMA_LIST_FINE_5_8(X) LUMA_LIST_TAKES_1_8(X) LUMA_LIST_TAKES_FINE(X) LUMA_LIST_TAKES_9_16(X) LUMA_LIST_TAKES_GENERAL(X) LUMA_LIST_SP(X) LUMA_LIST_COOP(X)

@@ -354,6 +354,16 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         };
 #undef LUMA_K
         k = table[split == 4 ? 2 : split == 2 ? 1 : 0][scene == SCENE_LDS_ALL][noise][from_hit];
+        // Frames taken inside waves for run-time sphere counts too, while the wave pools (16.6 KB per workgroup) leave seven
+        // workgroups per CU beside the scene: 1080p x 64 frames of 24 / 64 / 100 spheres 3.57 / 7.94 / 12.05 -> 3.42 / 7.35 / 11.62 ms,
+        // from hit points 5.59 / 13.16 / 20.01 -> 5.21 / 11.97 / 19.06; 150 spheres and up lose (319: 37.2 -> 50.6 ms with four
+        // workgroups per CU) -- tools/mid_scene_probe.py, profiles/r03/mid_scene_takes.txt
+        if (LUMA_TAKES_GENERAL && scene == SCENE_LDS_ALL && n <= kTakesGeneralSpheresMax && noise && split == 1 && !use_grid
+            && args.spp >= kStealSppMin && args.spp <= kStealSppMax) {
+            static const kernel_t takes_general[2] = { render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, false, 1, false, 0, 0, true>,
+                                                       render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, true, 1, false, 0, 0, true> };
+            k = takes_general[from_hit];
+        }
         // Scenes of up to 16 spheres (the reference's own has 5): instances with the sphere count as a compile-time
         // constant, their scans fully unrolled (config #3: 1.93 -> 1.84 ms, profiles/r02/ab_unrolled_scan.txt).  Round 3
         // took them from 8 to 16 spheres and to LUMA_FLAG_ORIGIN_FROM_HIT (tools/ns_reach_ab.py, profiles/r03/ns_reach_ab.txt:

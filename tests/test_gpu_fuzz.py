@@ -120,7 +120,7 @@ for n in range(1, 9):
 # scales that leave the lean sqrt / division windows, tie-prone kinds, hit-point origins, two accumulating calls
 for case in range(24):
     kind = ["mirror", "cluster", "wide", "around"][case % 4]
-    n = int(_rng.choice([1, 2, 5, 8, 9, 16]))
+    n = int(_rng.choice([1, 2, 5, 8, 9, 16, 24, 40]))
     CASES.append(dict(
         id=f"takes{case}-{kind}-n{n}", kind=kind, n=n, scale=float(_rng.choice([1.0, 1.0, 1e-3, 3e4])), seed=int(_rng.integers(1, 2**31)),
         W=int(_rng.integers(30, 200)), H=int(_rng.integers(3, 60)), spp=int(_rng.choice([2, 3, 5, 8, 9, 17, 40, 64, 128])),
