@@ -619,6 +619,9 @@ extern "C" int luma_dbg_timeline_copy(void* host, size_t bytes)
 #ifndef LUMA_STEAL_POOL
 #define LUMA_STEAL_POOL 256u
 #endif
+#ifndef LUMA_STEAL_POOL_GENERAL
+#define LUMA_STEAL_POOL_GENERAL 128u   // run-time sphere counts: the scene's records want the LDS (profiles/r03/mid_scene_takes.txt)
+#endif
 #ifndef LUMA_SPLIT_WAVES
 #define LUMA_SPLIT_WAVES 7
 #endif
@@ -765,9 +768,10 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? (SP
     // others take spp-1, spp-2, ... and park them; a claim is good while front + back < spp, so
     // the two ends meet wherever the lanes' luck puts them and no lane waits on a slower sibling.
     __shared__ uint32_t claim[SPL ? (WPK > WPKF ? WPK : WPKF) * 64 : 1];
-    __shared__ uint32_t steal_pool[STEAL ? WAVES * LUMA_STEAL_POOL * 4u : 1];
+    constexpr uint32_t kPool = NS > 0 ? LUMA_STEAL_POOL : LUMA_STEAL_POOL_GENERAL;   // slots per wave
+    __shared__ uint32_t steal_pool[STEAL ? WAVES * kPool * 4u : 1];
     __shared__ uint8_t steal_pairing[STEAL ? WAVES * 64 : 1];
-    static_assert(!STEAL || WAVES * LUMA_STEAL_POOL * 16u <= 32768u, "the pools of a workgroup's waves fit beside the scene");
+    static_assert(!STEAL || WAVES * kPool * 16u <= 32768u, "the pools of a workgroup's waves fit beside the scene");
     if (SPL && k == 0) { claim[cidx] = 0u; }
     f3 dir0 = mk3(0.f, 0.f, -1.f);
     float blur = 0.f, gainf = 1.f;
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? (SP
         uint32_t taken = kOwn, slot_out = kOwn, pool_used = 0, s_end = spp_all;
         bool steals = STEAL && lone;
         uint32_t rpix = pcg_first(pixel ^ A.key[0]);              // the pixel's word of the RNG counter, through its first step
-        uint32_t* const pool = steal_pool + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * (LUMA_STEAL_POOL * 4u) : 0u);
+        uint32_t* const pool = steal_pool + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * (kPool * 4u) : 0u);
         volatile uint8_t* const pairing = steal_pairing + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 64u : 0u);
 
         // One trip of the flat (sample, bounce) loop, in the four pieces the two loop skeletons below arrange:
@@ -943,7 +947,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? (SP
             const bool gives = have && s + 1u < s_end;
             const uint64_t giving = __ballot(gives);
             const uint32_t pairs = min(min((uint32_t)__builtin_popcountll(wanting), (uint32_t)__builtin_popcountll(giving)),
-                                       LUMA_STEAL_POOL - pool_used);
+                                       kPool - pool_used);
             // no pixel with a frame to give (none will come: unclaimed frames only go), or the pool is full: that was the last try
             if (pairs == 0u) { steals = false; return; }
             const uint64_t mine = have ? giving : wanting;

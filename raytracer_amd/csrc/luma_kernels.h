@@ -39,7 +39,10 @@ static constexpr uint32_t kStealSppMin = LUMA_STEAL_SPP_MIN;
 #ifndef LUMA_TAKES_GENERAL
 #define LUMA_TAKES_GENERAL 1
 #endif
-static constexpr uint32_t kTakesGeneralSpheresMax = 112;   // (16.6 KB of pools + 56 B per sphere) x 7 workgroups <= 160 KB
+#ifndef LUMA_TAKES_GENERAL_MAX
+#define LUMA_TAKES_GENERAL_MAX 256
+#endif
+static constexpr uint32_t kTakesGeneralSpheresMax = LUMA_TAKES_GENERAL_MAX;   // (8.4 KB of pools + 56 B per sphere) x 7 workgroups <= 160 KB
 
 // FLAG_GRID: scenes with at least this many spheres walk the grid wave-cooperatively (wave_grid_walk).
 static constexpr uint32_t kGridWaveWalkMin = 512;

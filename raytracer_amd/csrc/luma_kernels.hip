@@ -354,10 +354,11 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         };
 #undef LUMA_K
         k = table[split == 4 ? 2 : split == 2 ? 1 : 0][scene == SCENE_LDS_ALL][noise][from_hit];
-        // Frames taken inside waves for run-time sphere counts too, while the wave pools (16.6 KB per workgroup) leave seven
-        // workgroups per CU beside the scene: 1080p x 64 frames of 24 / 64 / 100 spheres 3.57 / 7.94 / 12.05 -> 3.42 / 7.35 / 11.62 ms,
-        // from hit points 5.59 / 13.16 / 20.01 -> 5.21 / 11.97 / 19.06; 150 spheres and up lose (319: 37.2 -> 50.6 ms with four
-        // workgroups per CU) -- tools/mid_scene_probe.py, profiles/r03/mid_scene_takes.txt
+        // Frames taken inside waves for run-time sphere counts too, with pools of 128 slots per wave (8.4 KB per workgroup) so that
+        // seven workgroups still fit a CU beside the scene's records: 1080p x 64 frames of 24 / 64 / 100 / 200 / 256 spheres
+        // 3.57 / 7.94 / 12.05 / 23.4 / 29.9 -> 3.42 / 7.42 / 11.16 / 21.8 / 29.1 ms, from hit points 5.59 / 13.2 / 20.0 / 39.8 / 50.8 ->
+        // 5.26 / 12.3 / 18.6 / 37.0 / 49.2; at 319 spheres it loses 4 % (and 256-slot pools lose 36 % there: four workgroups per
+        // CU) -- tools/mid_scene_probe.py, profiles/r03/mid_scene_takes.txt
         if (LUMA_TAKES_GENERAL && scene == SCENE_LDS_ALL && n <= kTakesGeneralSpheresMax && noise && split == 1 && !use_grid
             && args.spp >= kStealSppMin && args.spp <= kStealSppMax) {
             static const kernel_t takes_general[2] = { render_kernel<kLaneTileW, 4, SCENE_LDS_ALL, true, false, 1, false, 0, 0, true>,

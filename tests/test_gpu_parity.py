@@ -158,8 +158,8 @@ def test_frames_taken_inside_waves_vs_oracle(abi, oracle, W, H, spp, n, flags, f
 @pytest.mark.parametrize("W,H,spp,n,flags,limit", [(640, 360, 64, 5, 0, 8 << 20), (512, 300, 100, 5, 0, 0), (640, 360, 48, 3, 2, 1 << 20),
                                                    (97, 55, 128, 16, 0, 0),
                                                    (200, 150, 3, 5, 0, 0), (160, 90, 7, 5, 2, 0), (97, 55, 2, 8, 0, 0),    # 2 to 7 frames: no fine class
-                                                   (160, 90, 24, 40, 0, 0), (128, 72, 9, 100, 2, 0), (96, 54, 16, 17, 0, 0),   # run-time sphere counts (17-112)
-                                                   (96, 54, 16, 113, 0, 0)])                                             # ... and just past them
+                                                   (160, 90, 24, 40, 0, 0), (128, 72, 9, 100, 2, 0), (96, 54, 16, 17, 0, 0),   # run-time sphere counts (17-256)
+                                                   (96, 54, 16, 256, 0, 0), (96, 54, 64, 200, 2, 0), (96, 54, 16, 257, 0, 0)])   # ... to their end and just past it
 def test_frames_taken_on_a_small_frame_vs_the_whole_oracle_frame(abi, oracle, W, H, spp, n, flags, limit):
     """The TAKES instances run where a band has one lane per pixel: from 1.5 M pixels, or where four lanes' parking does
     not fit its budget.  luma_hip_set_park_limit makes small frames such bands (with a fine class as large as the limit
