@@ -614,7 +614,10 @@ extern "C" int luma_dbg_timeline_copy(void* host, size_t bytes)
 #define LUMA_DEFER_SPLIT2 0     // with two lanes per pixel: 2.5 % slower (profiles/r03/ab_frames_taken.txt)
 #endif
 #ifndef LUMA_DEFER_GENERAL
-#define LUMA_DEFER_GENERAL 0    // the same for run-time sphere counts: 9-12 % slower (profiles/r03/scene_size_sweep_deferral.txt)
+// run-time sphere counts: with bounce rays from hit points (both scans of a trip are general-origin ones) -9..-16 %; with
+// the reference's camera-origin bounce rays +-2 % at 16 / 64 frames per call and 9-12 % slower at 4 (2: for those too)
+// (profiles/r03/mid_scene_takes.txt, scene_size_sweep_deferral.txt)
+#define LUMA_DEFER_GENERAL 1
 #endif
 #ifndef LUMA_STEAL_POOL
 #define LUMA_STEAL_POOL 256u
@@ -674,7 +677,7 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? (SP
     constexpr bool PARK_BY_PIXEL = SPLIT == 4;
     // hits wait for company (see the loop skeletons below); not with two lanes per pixel (a band of two of the config #3
     // frame: 0.942 -> 0.965 ms with it, profiles/r03/ab_deferred_hits.txt) and not for the noise-free one-frame launches
-    constexpr bool DEFER = LUMA_DEFER && (NS > 0 || LUMA_DEFER_GENERAL) && !GRID && NOISE && (SPLIT != 2 || LUMA_DEFER_SPLIT2);
+    constexpr bool DEFER = LUMA_DEFER && (NS > 0 || (LUMA_DEFER_GENERAL && FROM_HIT) || LUMA_DEFER_GENERAL > 1) && !GRID && NOISE && (SPLIT != 2 || LUMA_DEFER_SPLIT2);
     // TAKES: lanes out of frames take frames of their wave's other pixels (STEAL below); instances of their own, because the
     // code costs launches that cannot gain from it (config #4, 256 frames per pixel: 22.7 ms without it, 23.4 with it
     // switched off at run time, profiles/r03/ab_frames_taken.txt); launch_render picks them up to kStealSppMax frames

@@ -6,7 +6,7 @@ sys.path.insert(0, '.')
 from raytracer_amd import abi
 W, H = 1920, 1080
 for flags in (0, abi.FLAG_ORIGIN_FROM_HIT):
-    for spp in (16, 64):
+    for spp in ([int(v) for v in sys.argv[1:]] or [16, 64]):
         out = []
         for n in (24, 48, 64, 100, 150, 200, 256, 319):
             with abi.Context(0) as ctx:
