@@ -118,6 +118,10 @@ static uint32_t choose_split(size_t band_pixels, uint32_t spp, uint32_t n_sphere
     // frame (1.04M / 691k / 518k / 415k / 346k px) with 4 lanes: 0.960 / 0.632 / 0.483 / 0.372 / 0.326, with 2: 0.970 / 0.645 /
     // 0.490 / 0.385 / 0.344, with 1 and a fine class: 0.810 / 0.577 / 0.453 / 0.354 / 0.329, with 1 and none: 0.881 / - / 0.489
     // (tools/split_sweep.sh, split_sweep2.sh, profiles/r03/split_sweep.txt)
+    // run-time sphere counts: the two-lane tier has gone (its instances neither defer hits nor take frames): 1080p x 64 spp bands
+    // of 540 rows of 64 / 200 spheres 4.58 / 12.10 ms with two lanes, 4.43 / 11.42 with four; from hit points 7.05 / 20.09 against
+    // 6.06 / 16.76 (tools/mid_scene_bands.py, profiles/r03/mid_scene_takes.txt)
+    if (n_spheres > kCompileTimeSpheresMax && !grid && split == 2) { split = 4; }
     if (takes_launch(spp, n_spheres, grid)) {
         const bool fine = fine_class_launch(1, spp, n_spheres, grid, from_hit);
         split = band_pixels >= (fine ? 380000u : 600000u) ? 1u : 4u;

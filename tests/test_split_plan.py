@@ -37,8 +37,9 @@ def test_lanes_per_pixel_where_no_frames_are_taken(abi):
     assert [abi.split_plan(W, rows, 4, 5).lanes for rows in (1080, 540, 270)] == [1, 2, 4]
     # hit-point origins have no fine class: one lane per pixel from 600k pixels
     assert [abi.split_plan(W, rows, 64, 5, flags=abi.FLAG_ORIGIN_FROM_HIT).lanes for rows in (1080, 540, 360, 270)] == [1, 1, 1, 4]
-    # more than 16 spheres: run-time sphere counts, no TAKES instances
-    assert [abi.split_plan(W, rows, 64, 64).lanes for rows in (1080, 540, 270)] == [1, 2, 4]
+    # more than 16 spheres (run-time sphere counts): one lane from 1.5M pixels, four below; the two-lane instances neither
+    # defer hits nor take frames and lose to both
+    assert [abi.split_plan(W, rows, 64, 64).lanes for rows in (1080, 540, 270)] == [1, 4, 4]
 
 
 def test_no_fine_class_below_eight_frames_or_with_many_rounds(abi):
