@@ -22,7 +22,8 @@
 extern "C" {
 #endif
 
-#define LUMA_HIP_ABI_VERSION 2   /* 2: luma_stats gained lanes_per_pixel / split_refused */
+#define LUMA_HIP_ABI_VERSION 3   /* 2: luma_stats gained lanes_per_pixel / split_refused; 3: luma_split_plan gained park_depth,
+                                    luma_gather_plan_describe, luma_hip_set_park_limit */
 
 enum {
     LUMA_OK       = 0,

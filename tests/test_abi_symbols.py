@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(abi):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/luma_hip.h but not exported"
     assert sorted(abi.SYMBOLS) == names
-    assert L.luma_hip_abi_version() == 2
+    assert L.luma_hip_abi_version() == 3
     assert L.luma_hip_strerror(0) == b"ok" and L.luma_hip_strerror(-1) == b"invalid argument"
 
 
