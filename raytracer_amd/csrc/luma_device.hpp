@@ -849,7 +849,11 @@ __global__ __launch_bounds__(WAVES * 64, GRID ? 6 : (LUMA_DEFER && NS > 0) ? (SP
         // by more than that and nothing is gained (config #4, 256 frames).
         constexpr uint32_t kOwn = 0xFFFFu;
         uint32_t taken = kOwn, slot_out = kOwn, pool_used = 0, s_end = spp_all;
+#ifdef LUMA_STEAL_NEVER
+        bool steals = false;                                     // probe builds: the code without its effect
+#else
         bool steals = STEAL && lone;
+#endif
         uint32_t rpix = pcg_first(pixel ^ A.key[0]);              // the pixel's word of the RNG counter, through its first step
         uint32_t* const pool = steal_pool + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * (kPool * 4u) : 0u);
         volatile uint8_t* const pairing = steal_pairing + (STEAL ? (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 64u : 0u);
